@@ -1,0 +1,67 @@
+"""ctypes binding of libdsrg_hip.so (include/dsrg_hip.h).  There is no fallback: if the library
+is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsrg_hip.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
+MAX_GROUPS = 8
+ABI_VERSION = 1
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p),
+                ('C', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    'dsrg_abi_version': (C.c_int, []),
+    'dsrg_last_error': (C.c_char_p, []),
+    'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
+    'dsrg_attention_fwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _P, _P,
+                                     _I, _I, _I, _I, _F, _I, _P]),
+    'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
+    'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
+                                    _P, _I, _I, _I, _I, _P]),
+    'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class DsrgHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every symbol of include/dsrg_hip.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DsrgHipError('%s not found: build it with `python -m dsrg_amd.build` (hipcc, gfx950); '
+                           'there is no non-HIP fallback for the DSRG hot path' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    v = lib.dsrg_abi_version()
+    if v != ABI_VERSION:
+        raise DsrgHipError('libdsrg_hip.so ABI version %d, binding expects %d' % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DsrgHipError('%s failed (%d): %s' % (what, rc, load().dsrg_last_error().decode()))

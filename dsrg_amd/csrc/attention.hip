@@ -1,0 +1,142 @@
+// Fused short-sequence attention (head dim 64), fp32 arithmetic on the vector ALU with K/V tiles
+// staged once per workgroup in LDS and an online softmax over 64-key tiles, so any Nk works and no
+// score matrix ever reaches HBM.  This is the exact-fp32 path (parity mode) and the generic fallback;
+// the mask term, the sprel bias w*d+b and the "+1 bool mask" quirk are formed in-kernel.
+//   grid = (ceil(Nq/16), NH, B), 256 threads = 4 waves, each wave owns 4 query rows.
+//   scores : lane <-> key   (K tile rows padded to 68 floats: conflict-free ds_read_b128)
+//   P·V    : lane <-> d     (V tile row-major: conflict-free ds_read_b32, P broadcast from LDS)
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64, KT = 64, QW = 4, QPB = 16, KPAD = 68;
+
+struct AttnArgs {
+  const void *Q, *K, *V; void* O;
+  int64_t q_bs, k_bs, v_bs, o_bs;
+  int q_rs, k_rs, v_rs, o_rs;
+  const uint8_t* kmask; int mask_mode;
+  const float* dists; const float* sprel_w; const float* sprel_b;
+  int Nq, Nk; float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
+  __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
+  __shared__ __attribute__((aligned(16))) float Ps[4 * KT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QPB;
+  const T* Qp = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * DH;
+  const T* Kp = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * DH;
+  const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
+  T* Op = reinterpret_cast<T*>(a.O) + b * a.o_bs + h * DH;
+
+  // stage the block's 16 query rows (zero beyond Nq)
+  {
+    const int r = tid >> 4, c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q0 + r < a.Nq) v = ld4(Qp + (size_t)(q0 + r) * a.q_rs + c);
+    *reinterpret_cast<float4*>(&Qs[r * DH + c]) = v;
+  }
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+
+  float m[QW], l[QW], o[QW];
+#pragma unroll
+  for (int i = 0; i < QW; ++i) { m[i] = -INFINITY; l[i] = 0.f; o[i] = 0.f; }
+
+  for (int k0 = 0; k0 < a.Nk; k0 += KT) {
+    __syncthreads();   // previous tile fully consumed (also orders the Qs writes on the first pass)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k0 + r < a.Nk) {
+        kv = ld4(Kp + (size_t)(k0 + r) * a.k_rs + c);
+        vv = ld4(Vp + (size_t)(k0 + r) * a.v_rs + c);
+      }
+      *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = kv;
+      *reinterpret_cast<float4*>(&Vs[r * DH + c]) = vv;
+    }
+    __syncthreads();
+
+    const int key = k0 + lane;
+    float mterm = 0.f;
+    bool dead = key >= a.Nk;
+    if (!dead && a.kmask) {
+      const bool mk = a.kmask[(size_t)b * a.Nk + key] != 0;
+      if (a.mask_mode == DSRG_MASK_NEG10000) mterm = mk ? 0.f : -10000.0f;
+      else if (a.mask_mode == DSRG_MASK_NEGINF) dead = !mk;
+      else if (a.mask_mode == DSRG_MASK_PLUS1) mterm = mk ? 1.0f : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+      const int ql = wave * QW + i, qg = q0 + ql;
+      if (qg >= a.Nq) continue;                     // wave-uniform
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(&Ks[lane * KPAD + c]);
+        const float4 qq = *reinterpret_cast<const float4*>(&Qs[ql * DH + c]);
+        s = fmaf(qq.x, kk.x, s); s = fmaf(qq.y, kk.y, s); s = fmaf(qq.z, kk.z, s); s = fmaf(qq.w, kk.w, s);
+      }
+      s = s * a.scale + mterm;
+      if (a.dists && !dead) s += a.dists[((size_t)b * a.Nq + qg) * a.Nk + key] * sw + sb;
+      if (dead) s = -INFINITY;
+      const float mn = fmaxf(m[i], wave_max(s));
+      const float alpha = (m[i] == -INFINITY) ? 0.f : __expf(m[i] - mn);
+      const float p = (s == -INFINITY) ? 0.f : __expf(s - mn);
+      l[i] = l[i] * alpha + wave_sum(p);
+      m[i] = mn;
+      Ps[wave * KT + lane] = p;                     // wave-private row: no barrier needed, wave is in lockstep
+      __builtin_amdgcn_wave_barrier();
+      float acc = o[i] * alpha;
+#pragma unroll 8
+      for (int j = 0; j < KT; j += 4) {
+        const float4 pp = *reinterpret_cast<const float4*>(&Ps[wave * KT + j]);
+        acc = fmaf(pp.x, Vs[(j + 0) * DH + lane], acc);
+        acc = fmaf(pp.y, Vs[(j + 1) * DH + lane], acc);
+        acc = fmaf(pp.z, Vs[(j + 2) * DH + lane], acc);
+        acc = fmaf(pp.w, Vs[(j + 3) * DH + lane], acc);
+      }
+      o[i] = acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int qg = q0 + wave * QW + i;
+    if (qg >= a.Nq) continue;
+    Elem<T>::st(Op + (size_t)qg * a.o_rs + lane, o[i] / l[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                                  const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
+                                  const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                                  const float* sprel_w, const float* sprel_b,
+                                  int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream) {
+  DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_fwd: bad dtype %d", dtype);
+  DSRG_CHECK(Q && K && V && O, "dsrg_attention_fwd: null Q/K/V/O");
+  DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0 && Nk >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_fwd: bad dims B=%d NH=%d Nq=%d Nk=%d", B, NH, Nq, Nk);
+  DSRG_CHECK(mask_mode >= DSRG_MASK_NONE && mask_mode <= DSRG_MASK_PLUS1, "dsrg_attention_fwd: bad mask_mode %d", mask_mode);
+  DSRG_CHECK(mask_mode == DSRG_MASK_NONE || kmask, "dsrg_attention_fwd: mask_mode %d needs kmask", mask_mode);
+  DSRG_CHECK(!pair_dists || (sprel_w && sprel_b), "dsrg_attention_fwd: pair_dists needs sprel_w and sprel_b");
+  const int al = dtype == DSRG_BF16 ? 4 : 4;
+  DSRG_CHECK(q_rs % al == 0 && k_rs % al == 0 && v_rs % al == 0 && q_bs % al == 0 && k_bs % al == 0 && v_bs % al == 0,
+             "dsrg_attention_fwd: strides must be multiples of %d elements", al);
+  DSRG_CHECK(q_rs >= NH * 64 && k_rs >= NH * 64 && v_rs >= NH * 64 && o_rs >= NH * 64, "dsrg_attention_fwd: row strides smaller than NH*64");
+  const uintptr_t am = dtype == DSRG_BF16 ? 7 : 15;
+  DSRG_CHECK(((uintptr_t)Q & am) == 0 && ((uintptr_t)K & am) == 0 && ((uintptr_t)V & am) == 0, "dsrg_attention_fwd: misaligned Q/K/V");
+  if (B == 0 || Nq == 0) return DSRG_OK;
+  AttnArgs a{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask, mask_mode,
+             pair_dists, sprel_w, sprel_b, Nq, Nk, scale};
+  dim3 grid((Nq + QPB - 1) / QPB, NH, B), block(256);
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
+  DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
+  return DSRG_OK;
+}

@@ -1,0 +1,76 @@
+// Shared device/host helpers for libdsrg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dsrg_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+
+// f32 -> bf16, round-to-nearest-even, NaN stays NaN (compiler emits v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int PER16 = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int PER16 = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load / store 4 consecutive elements as float4 (pointer 8B-aligned for bf16, 16B for f32)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  uint2 u;
+  u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+  u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// host side
+void dsrg_set_error(const char* fmt, ...);
+#define DSRG_CHECK(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) {                            \
+      dsrg_set_error(__VA_ARGS__);            \
+      return DSRG_EINVAL;                     \
+    }                                         \
+  } while (0)
+#define DSRG_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      dsrg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return DSRG_ELAUNCH;                                                   \
+    }                                                                        \
+  } while (0)

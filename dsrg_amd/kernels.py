@@ -1,0 +1,217 @@
+"""Raw launches of the libdsrg_hip.so kernels on torch tensors (no autograd; see functional.py).
+
+Tensors must live on a ROCm device; the work is enqueued on torch's current stream.  Outputs are
+allocated with torch.empty (caching allocator: capturable in a HIP graph)."""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import F32, BF16
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise _lib.DsrgHipError('unsupported dtype %s (float32 / bfloat16 only)' % (t,))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.DsrgHipError('dsrg_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
+    return t
+
+
+def _rows(t):
+    """[..., H] tensor -> (M, ld) treating it as rows; requires unit stride on the last dim and
+    uniform row stride."""
+    if t.dim() == 1:
+        return 1, t.shape[0]
+    if t.stride(-1) != 1:
+        raise _lib.DsrgHipError('last dim must be contiguous')
+    if t.dim() == 2:
+        return t.shape[0], t.stride(0)
+    ld = t.stride(-2)
+    M = 1
+    for d in range(t.dim() - 1):
+        M *= t.shape[d]
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):       # check the leading dims collapse onto one stride
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise _lib.DsrgHipError('tensor rows are not uniformly strided: %s %s' % (tuple(t.shape), t.stride()))
+        exp *= t.shape[d]
+    return M, ld
+
+
+def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None):
+    """problems: list of (x [..,K], w [N,K], bias fp32 [N] | None, residual [..,N] | None).
+    Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32)."""
+    lib = _lib.load()
+    n = len(problems)
+    arr = (_lib.GemmProblem * n)()
+    res = []
+    dt = _dt(problems[0][0])
+    for i, (x, w, b, r) in enumerate(problems):
+        _dev(x)
+        if _dt(x) != dt or w.dtype != x.dtype:
+            raise _lib.DsrgHipError('gemm: mixed dtypes in one grouped launch')
+        M, lda = _rows(x)
+        N, K = w.shape
+        if x.shape[-1] != K:
+            raise _lib.DsrgHipError('gemm: x[..,%d] vs w[%d,%d]' % (x.shape[-1], N, K))
+        if outs is not None and outs[i] is not None:
+            out = outs[i]
+        else:
+            out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+        Mo, ldc = _rows(out)
+        ldr = 0
+        if r is not None:
+            Mr, ldr = _rows(r)
+            if r.dtype != x.dtype or Mr != M:
+                raise _lib.DsrgHipError('gemm: residual must match x rows/dtype')
+        if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+            raise _lib.DsrgHipError('gemm: bias must be contiguous fp32')
+        if Mo != M or w.stride(1) != 1:
+            raise _lib.DsrgHipError('gemm: bad out rows / weight layout')
+        arr[i] = _lib.GemmProblem(_p(x), _p(w), _p(b), _p(r), _p(out), M, N, K, lda, w.stride(0), ldr, ldc)
+        res.append(out)
+    odt = F32 if out_f32 else dt
+    _lib.check(lib.dsrg_gemm_nt(arr, n, dt, odt, act, _stream()), 'dsrg_gemm_nt')
+    return res
+
+
+def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125):
+    """q [B,Nq,nh*64], k/v [B,Nk,nh*64] views (row/batch strides free, last dim contiguous)."""
+    lib = _lib.load()
+    _dev(q)
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.dtype != q.dtype:
+            raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes equal')
+    out = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
+    if kmask is not None:
+        if kmask.dtype != torch.bool or kmask.shape != (B, Nk) or not kmask.is_contiguous():
+            raise _lib.DsrgHipError('attention: kmask must be contiguous bool [B,Nk]')
+    if dists is not None:
+        if dists.dtype != torch.float32 or dists.shape != (B, Nq, Nk) or not dists.is_contiguous():
+            raise _lib.DsrgHipError('attention: pair_dists must be contiguous fp32 [B,Nq,Nk]')
+    bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
+    _lib.check(lib.dsrg_attention_fwd(
+        _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1),
+        _p(out), out.stride(0), out.stride(1), _p(kmask), mask_mode, _p(dists), _p(sprel_w), _p(sprel_b),
+        B, nh, Nq, Nk, float(scale), _dt(q), _stream()), 'dsrg_attention_fwd')
+    return out
+
+
+def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
+    lib = _lib.load()
+    _dev(x)
+    M, ldx = _rows(x)
+    H = x.shape[-1]
+    out_dtype = out_dtype or (residual.dtype if residual is not None else x.dtype)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    Mo, ldo = _rows(out)
+    ldr = _rows(residual)[1] if residual is not None else 0
+    _lib.check(lib.dsrg_layernorm_fwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), _p(out), ldo, M, H,
+                                      float(eps), _dt(x), _dt(out), _stream()), 'dsrg_layernorm_fwd')
+    return out
+
+
+def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(M, H, device=device, dtype=dtype)
+    _dev(out)
+    ldo = _rows(out)[1]
+    ldb = _rows(base)[1] if base is not None else 0
+    F_, ldf = (feat.shape[-1], _rows(feat)[1]) if feat is not None else (0, 0)
+    for t in (idx1, idx2):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise _lib.DsrgHipError('embed_ln: indices must be contiguous int32')
+    if base is not None and base.dtype != out.dtype:
+        raise _lib.DsrgHipError('embed_ln: base dtype must match out dtype')
+    lnf_g, lnf_b = lnf if lnf is not None else (None, None)
+    lno_g, lno_b = lno if lno is not None else (None, None)
+    _lib.check(lib.dsrg_embed_ln_fwd(_p(base), ldb, _p(feat), ldf, F_, _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b),
+                                     _p(E1), _p(idx1), _p(E2), _p(idx2), _p(vec), _p(lno_g), _p(lno_b),
+                                     float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd')
+    return out
+
+
+def group_mean(x, G, out=None):
+    """x [M*G, H] -> [M, H] mean over consecutive groups of G rows."""
+    lib = _lib.load()
+    _dev(x)
+    MG, ldx = _rows(x)
+    H = x.shape[-1]
+    M = MG // G
+    if out is None:
+        out = torch.empty(M, H, device=x.device, dtype=x.dtype)
+    _lib.check(lib.dsrg_group_mean_fwd(_p(x), ldx, _p(out), _rows(out)[1], M, G, H, _dt(x), _stream()),
+               'dsrg_group_mean_fwd')
+    return out
+
+
+def gaa_pool(x, w, b):
+    lib = _lib.load()
+    _dev(x)
+    if not x.is_contiguous():
+        raise _lib.DsrgHipError('gaa_pool: x must be contiguous [B,V,H]')
+    B, V, H = x.shape
+    out = torch.empty(B, H, device=x.device, dtype=x.dtype)
+    _lib.check(lib.dsrg_gaa_pool_fwd(_p(x), _p(w), _p(b), _p(out), B, V, H, _dt(x), _stream()), 'dsrg_gaa_pool_fwd')
+    return out
+
+
+def head_tail(h, gamma, beta, w2, b2, eps=1e-12):
+    lib = _lib.load()
+    _dev(h)
+    M, ldh = _rows(h)
+    H = h.shape[-1]
+    if h.dtype != torch.float32:
+        raise _lib.DsrgHipError('head_tail: h must be fp32')
+    score = torch.empty(h.shape[:-1], device=h.device, dtype=torch.float32)
+    _lib.check(lib.dsrg_head_tail_fwd(_p(h), ldh, _p(gamma), _p(beta), _p(w2), _p(b2), float(eps), _p(score), M, H,
+                                      _stream()), 'dsrg_head_tail_fwd')
+    return score
+
+
+def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
+    lib = _lib.load()
+    _dev(g_raw)
+    B, G = g_raw.shape
+    Vp = l_raw.shape[1]
+    for t in (g_raw, l_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
+        if not t.is_contiguous():
+            raise _lib.DsrgHipError('nav_logits: inputs must be contiguous')
+    gl, ll, fl = torch.empty_like(g_raw), torch.empty_like(l_raw), torch.empty_like(g_raw)
+    _lib.check(lib.dsrg_nav_logits_fwd(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gmap_masks), _p(gmap_visited),
+                                       _p(vp_nav_masks), _p(gmap_src), _p(bw_mask), _p(gl), _p(ll), _p(fl),
+                                       B, G, Vp, _stream()), 'dsrg_nav_logits_fwd')
+    return gl, ll, fl
+
+
+def igl_blend(aug, x, wa, ba, wo, bo):
+    lib = _lib.load()
+    _dev(x)
+    if not (aug.is_contiguous() and x.is_contiguous()):
+        raise _lib.DsrgHipError('igl_blend: inputs must be contiguous')
+    H = x.shape[-1]
+    M = x.numel() // H
+    out = torch.empty_like(x)
+    _lib.check(lib.dsrg_igl_blend_fwd(_p(aug), _p(x), _p(wa), _p(ba), _p(wo), _p(bo), _p(out), M, H, _dt(x),
+                                      _stream()), 'dsrg_igl_blend_fwd')
+    return out

@@ -1,0 +1,575 @@
+"""MI355X-native DSRG navigation-policy network (R2R and REVERIE variants).
+
+Drop-in for the reference's `GlocalTextPathNavCMT` (finetune_src/models/vilmodel.py:630-858 and
+vilmodel_reverie.py:634-874): same constructor (a config object), same `forward(mode, batch)` with
+modes 'language' / 'panorama' / 'navigation', same return structure, same `state_dict()` keys and shapes
+(499 tensors R2R / 503 REVERIE) so reference checkpoints load unchanged, `from_pretrained(None, config=,
+state_dict=)` with the reference's 'bert.' prefix handling (vlnbert_init.py:58-66,110-113).
+
+What is different is how it computes: the module tree only HOLDS parameters; `forward` drives the
+hand-written gfx950 kernels of libdsrg_hip.so through dsrg_amd.functional:
+  * Q/K/V projections are packed into one GEMM; global and local x-layer branches run as ONE grouped
+    GEMM launch per sub-layer; the three RMF poolers and the SAP/OG heads are grouped the same way;
+  * the 16 text K/V projections of the 8 x-layers (step-invariant, vilmodel.py:351-352 recomputes them
+    every step) are one [B*L,768]x[768,12288] GEMM, cached per txt_embeds tensor in no-grad mode;
+  * attention is one fused kernel per call (mask term, sprel bias w*d+b and the "+1 bool mask" quirk
+    formed in-kernel); token-embedding sums+LayerNorms, GAA pooling, head tails and the logit fusion
+    are single kernels; the viewpoint-id string matching of the fusion loop (vilmodel.py:788-805) is
+    done once on the host into two small index tensors.
+Compute dtype is bfloat16 (default) or float32 (exact-fp32 MFMA: the parity mode).
+"""
+import math
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as Fn, kernels as K
+from ._lib import (ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1,
+                   DsrgHipError)
+
+
+# --------------------------------------------------------------------------- parameter tree
+def _mod(**children):
+    m = nn.Module()
+    for k, v in children.items():
+        setattr(m, k, v)
+    return m
+
+
+def _qkv(h, ctx=None):
+    return _mod(query=nn.Linear(h, h), key=nn.Linear(ctx or h, h), value=nn.Linear(ctx or h, h))
+
+
+def _dense_ln(i, o, eps):
+    return _mod(dense=nn.Linear(i, o), LayerNorm=nn.LayerNorm(o, eps=eps))
+
+
+def _self_att(h, eps):
+    m = nn.Module()
+    setattr(m, 'self', _qkv(h))
+    m.output = _dense_ln(h, h, eps)
+    return m
+
+
+def _bert_layer(h, ff, eps):
+    return _mod(attention=_self_att(h, eps), intermediate=_mod(dense=nn.Linear(h, ff)), output=_dense_ln(ff, h, eps))
+
+
+def _x_layer(cfg):
+    h, ff, eps = cfg.hidden_size, cfg.intermediate_size, cfg.layer_norm_eps
+    m = nn.Module()
+    if getattr(cfg, 'use_lang2visn_attn', False):
+        m.lang_self_att, m.lang_inter, m.lang_output = _self_att(h, eps), _mod(dense=nn.Linear(h, ff)), _dense_ln(ff, h, eps)
+    m.visn_self_att, m.visn_inter, m.visn_output = _self_att(h, eps), _mod(dense=nn.Linear(h, ff)), _dense_ln(ff, h, eps)
+    m.visual_attention = _mod(att=_qkv(h), output=_dense_ln(h, h, eps))
+    return m
+
+
+def _x_encoder(cfg):
+    return _mod(x_layers=nn.ModuleList([_x_layer(cfg) for _ in range(cfg.num_x_layers)]))
+
+
+def _cls_head(h, inp=None, out=1):
+    return _mod(net=nn.Sequential(nn.Linear(inp or h, h), nn.ReLU(), nn.LayerNorm(h, eps=1e-12), nn.Linear(h, out)))
+
+
+def _pano_layer(h, ff):
+    sa = _mod(out_proj=nn.Linear(h, h))
+    sa.in_proj_weight = nn.Parameter(torch.empty(3 * h, h))
+    sa.in_proj_bias = nn.Parameter(torch.zeros(3 * h))
+    return _mod(self_attn=sa, linear1=nn.Linear(h, ff), linear2=nn.Linear(ff, h),
+                norm1=nn.LayerNorm(h), norm2=nn.LayerNorm(h))
+
+
+def _img_embeddings(cfg, reverie):
+    h, d, a = cfg.hidden_size, cfg.obj_v2_size, cfg.angle_feat_size
+    m = nn.Module()
+    m.img_linear, m.img_layer_norm = nn.Linear(cfg.image_feat_size, h), nn.LayerNorm(h, eps=1e-12)
+    m.loc_linear, m.loc_layer_norm = nn.Linear(a + 3, h), nn.LayerNorm(h, eps=1e-12)
+    m.adaptive_pano_attn = nn.Linear(h, 1)
+    if reverie:
+        m.obj_reverie_linear, m.obj_reverie_layer_norm = nn.Linear(h, h), nn.LayerNorm(h, eps=1e-12)
+    m.obj_bbox_linear = nn.Linear(a + 3, d)
+    m.obj_name_linear = nn.Embedding(cfg.obj_name_vocab_size, d)
+    m.obj_nav_type_embedding = nn.Embedding(3, d)
+    m.obj_layer_norm = nn.LayerNorm(d, eps=1e-12)
+    # NB intermediate size stays 3072 on the 128-d object tokens (vilmodel.py:569-573 copies the config)
+    m.obj_self_encoder = _mod(layer=nn.ModuleList([_bert_layer(d, cfg.intermediate_size, cfg.layer_norm_eps) for _ in range(2)]))
+    m.obj_attn = _mod()
+    m.obj_attn.attn = nn.Parameter(torch.empty(d, 1).uniform_(-0.1, 0.1))      # in state_dict, unused in forward
+    m.vis_obj_linear = nn.Sequential(nn.Linear(h + d, h), nn.LayerNorm(h, eps=1e-12))
+    m.nav_type_embedding = nn.Embedding(3, h)
+    m.layer_norm = nn.LayerNorm(h, eps=1e-12)
+    m.pano_encoder = _mod(layers=nn.ModuleList([_pano_layer(h, cfg.intermediate_size) for _ in range(cfg.num_pano_layers)]),
+                          norm=nn.LayerNorm(h, eps=1e-12))
+    return m
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class GlocalTextPathNavCMT(nn.Module):
+    REVERIE = False
+    base_model_prefix = 'bert'
+
+    def __init__(self, config, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = cfg = config
+        self.compute_dtype = compute_dtype
+        h, eps = cfg.hidden_size, cfg.layer_norm_eps
+        emb = nn.Module()
+        emb.word_embeddings = nn.Embedding(cfg.vocab_size, h, padding_idx=0)
+        emb.position_embeddings = nn.Embedding(cfg.max_position_embeddings, h)
+        emb.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, h)
+        emb.act_embedding = nn.Embedding(cfg.word_max_action, h)
+        emb.obj_embedding = nn.Embedding(cfg.word_max_object, h)
+        emb.LayerNorm = nn.LayerNorm(h, eps=eps)
+        self.embeddings = emb
+
+        le = nn.Module()
+        le.layer = nn.ModuleList([_bert_layer(h, cfg.intermediate_size, eps) for _ in range(cfg.num_l_layers)])
+        le.act_obj_token_emb = nn.Embedding(1 if self.REVERIE else 2, h)       # unused in forward
+        le.instr_actobj_encoder = _qkv(h)
+        le.instr_aug_linear, le.instr_ori_linear = nn.Linear(h, 1), nn.Linear(h, 1)
+        le.instr_fuse_layernorm = nn.LayerNorm(h, eps=eps)                      # unused in forward
+        self.lang_encoder = le
+
+        self.img_embeddings = _img_embeddings(cfg, self.REVERIE)
+        self.local_encoder = _mod(
+            vp_pos_embeddings=nn.Sequential(nn.Linear(cfg.angle_feat_size * 2 + 6, h), nn.LayerNorm(h, eps=1e-12)),
+            encoder=_x_encoder(cfg))
+        ge = _mod(gmap_pos_embeddings=nn.Sequential(nn.Linear(cfg.angle_feat_size + 3, h), nn.LayerNorm(h, eps=1e-12)),
+                  gmap_step_embeddings=nn.Embedding(cfg.max_action_steps, h), encoder=_x_encoder(cfg))
+        ge.sprel_linear = nn.Linear(1, 1) if cfg.graph_sprels else None
+        self.global_encoder = ge
+        self.global_sap_head, self.local_sap_head = _cls_head(h), _cls_head(h)
+        self.sap_fuse_linear = _cls_head(h, inp=2 * h) if cfg.glocal_fuse else None
+        if cfg.obj_feat_size > 0:
+            self.og_head = _cls_head(h)
+        # RMF (vilmodel.py:652-657)
+        self.gmap_pooler, self.vp_pooler, self.txt_pooler = (_mod(dense=nn.Linear(h, h)) for _ in range(3))
+        self.local_his_map = nn.Linear(3 * h, h)
+        self.local_his_ln = nn.LayerNorm(h, eps=eps)
+
+        self.init_weights()
+        self._apply_freeze_flags()
+        self._wcache, self._kv_cache = None, None
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
+
+    # ---------------------------------------------------------------- construction helpers
+    def init_weights(self):
+        std = getattr(self.config, 'initializer_range', 0.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0.0, std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, 0.0, std)
+                if m.padding_idx is not None:
+                    with torch.no_grad():
+                        m.weight[m.padding_idx].zero_()
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        for lyr in self.img_embeddings.pano_encoder.layers:
+            nn.init.xavier_uniform_(lyr.self_attn.in_proj_weight)
+
+    def _apply_freeze_flags(self):  # vilmodel.py:662-676
+        cfg = self.config
+        frz = lambda mods: [p.requires_grad_(False) for m in mods for p in m.parameters()]
+        if not getattr(cfg, 'update_lang_bert', True):
+            frz([self.lang_encoder.layer])
+        if getattr(cfg, 'fix_lang_embedding', False) or getattr(cfg, 'fix_local_branch', False):
+            frz([self.embeddings, self.lang_encoder])
+        if getattr(cfg, 'fix_pano_embedding', False) or getattr(cfg, 'fix_local_branch', False):
+            frz([self.img_embeddings])
+        if getattr(cfg, 'fix_local_branch', False):
+            frz([self.local_encoder, self.local_sap_head] + ([self.og_head] if hasattr(self, 'og_head') else []))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kw):
+        """HF-style entry the reference uses (vlnbert_init.py:110-113): random init, then load the given
+        state_dict with a leading 'bert.' stripped; unknown / missing keys are tolerated; returns .eval()."""
+        if pretrained_model_name_or_path is not None:
+            raise DsrgHipError('by-name checkpoints are not supported offline; pass state_dict=')
+        model = cls(config, **kw)
+        if state_dict:
+            pre = cls.base_model_prefix + '.'
+            sd = {(k[len(pre):] if k.startswith(pre) else k): v for k, v in state_dict.items()}
+            own = model.state_dict()
+            sd = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+            model.load_state_dict(sd, strict=False)
+        return model.eval()
+
+    def invalidate_caches(self):
+        self._wcache, self._kv_cache = None, None
+
+    def train(self, mode=True):
+        self.invalidate_caches()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_caches()
+        return super()._apply(fn, *a, **k)
+
+    # ---------------------------------------------------------------- packed weights
+    def _weights(self):
+        """Compute-dtype / packed views of the parameters.  Cached when autograd is off; rebuilt with
+        differentiable ops (cat / to) when it is on, so gradients reach the fp32 master parameters."""
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not grad and self._wcache is not None:
+            return self._wcache
+        cd = self.compute_dtype
+        c = lambda t: t.to(cd).contiguous()
+        f = lambda t: t.float().contiguous()
+        W = {}
+
+        def lin(key, m):
+            W[key + '.w'], W[key + '.b'] = c(m.weight), f(m.bias)
+
+        def ln(key, m):
+            W[key + '.g'], W[key + '.b'] = f(m.weight), f(m.bias)
+
+        def packed(key, mods):
+            W[key + '.w'] = c(torch.cat([m.weight for m in mods], 0))
+            W[key + '.b'] = f(torch.cat([m.bias for m in mods], 0))
+
+        def bert_layer(key, L):
+            packed(key + '.qkv', [L.attention.self.query, L.attention.self.key, L.attention.self.value])
+            lin(key + '.ao', L.attention.output.dense); ln(key + '.aln', L.attention.output.LayerNorm)
+            lin(key + '.ff1', L.intermediate.dense); lin(key + '.ff2', L.output.dense); ln(key + '.fln', L.output.LayerNorm)
+
+        e, le, ie = self.embeddings, self.lang_encoder, self.img_embeddings
+        for k, m in (('emb.word', e.word_embeddings), ('emb.pos', e.position_embeddings), ('emb.type', e.token_type_embeddings),
+                     ('emb.act', e.act_embedding), ('emb.obj', e.obj_embedding)):
+            W[k] = f(m.weight)
+        ln('emb.ln', e.LayerNorm)
+        for i, L in enumerate(le.layer):
+            bert_layer('lang.%d' % i, L)
+        lin('igl.q', le.instr_actobj_encoder.query)
+        packed('igl.kv', [le.instr_actobj_encoder.key, le.instr_actobj_encoder.value])
+        for k, m in (('igl.aug', le.instr_aug_linear), ('igl.ori', le.instr_ori_linear)):
+            W[k + '.w'], W[k + '.b'] = f(m.weight.reshape(-1)), f(m.bias)
+
+        lin('img.lin', ie.img_linear); ln('img.ln', ie.img_layer_norm)
+        W['loc.w'], W['loc.b'] = f(ie.loc_linear.weight), f(ie.loc_linear.bias); ln('loc.ln', ie.loc_layer_norm)
+        W['gaa.w'], W['gaa.b'] = f(ie.adaptive_pano_attn.weight.reshape(-1)), f(ie.adaptive_pano_attn.bias)
+        if self.REVERIE:
+            lin('objv1.lin', ie.obj_reverie_linear); ln('objv1.ln', ie.obj_reverie_layer_norm)
+        W['obj.bbox.w'], W['obj.bbox.b'] = f(ie.obj_bbox_linear.weight), f(ie.obj_bbox_linear.bias)
+        W['obj.name'], W['obj.nav'] = f(ie.obj_name_linear.weight), f(ie.obj_nav_type_embedding.weight)
+        ln('obj.ln', ie.obj_layer_norm)
+        for i, L in enumerate(ie.obj_self_encoder.layer):
+            bert_layer('objenc.%d' % i, L)
+        lin('visobj.lin', ie.vis_obj_linear[0]); ln('visobj.ln', ie.vis_obj_linear[1])
+        W['nav_type'] = f(ie.nav_type_embedding.weight)
+        ln('pano.ln', ie.layer_norm)
+        for i, L in enumerate(ie.pano_encoder.layers):
+            k = 'pano.%d' % i
+            ln(k + '.n1', L.norm1); ln(k + '.n2', L.norm2)
+            W[k + '.qkv.w'], W[k + '.qkv.b'] = c(L.self_attn.in_proj_weight), f(L.self_attn.in_proj_bias)
+            lin(k + '.ao', L.self_attn.out_proj); lin(k + '.ff1', L.linear1); lin(k + '.ff2', L.linear2)
+        ln('pano.norm', ie.pano_encoder.norm)
+
+        ge, lo = self.global_encoder, self.local_encoder
+        W['gmap.step'] = f(ge.gmap_step_embeddings.weight)
+        W['gmap.pos.w'], W['gmap.pos.b'] = f(ge.gmap_pos_embeddings[0].weight), f(ge.gmap_pos_embeddings[0].bias)
+        ln('gmap.pos.ln', ge.gmap_pos_embeddings[1])
+        W['vp.pos.w'], W['vp.pos.b'] = f(lo.vp_pos_embeddings[0].weight), f(lo.vp_pos_embeddings[0].bias)
+        ln('vp.pos.ln', lo.vp_pos_embeddings[1])
+        if ge.sprel_linear is not None:
+            W['sprel.w'], W['sprel.b'] = f(ge.sprel_linear.weight.reshape(-1)), f(ge.sprel_linear.bias)
+        kv = []
+        for br, enc in (('g', ge.encoder), ('l', lo.encoder)):
+            for i, L in enumerate(enc.x_layers):
+                k = 'x.%s.%d' % (br, i)
+                lin(k + '.cq', L.visual_attention.att.query)
+                kv += [L.visual_attention.att.key, L.visual_attention.att.value]
+                lin(k + '.co', L.visual_attention.output.dense); ln(k + '.cln', L.visual_attention.output.LayerNorm)
+                packed(k + '.qkv', [L.visn_self_att.self.query, L.visn_self_att.self.key, L.visn_self_att.self.value])
+                lin(k + '.so', L.visn_self_att.output.dense); ln(k + '.sln', L.visn_self_att.output.LayerNorm)
+                lin(k + '.ff1', L.visn_inter.dense); lin(k + '.ff2', L.visn_output.dense); ln(k + '.fln', L.visn_output.LayerNorm)
+        packed('x.txtkv', kv)       # [2 branches * layers * (K,V) * 768, 768]
+        heads = [('head.g', self.global_sap_head), ('head.l', self.local_sap_head)]
+        if self.sap_fuse_linear is not None:
+            heads.append(('head.f', self.sap_fuse_linear))
+        if hasattr(self, 'og_head'):
+            heads.append(('head.o', self.og_head))
+        for k, hd in heads:
+            lin(k + '.l1', hd.net[0]); ln(k + '.ln', hd.net[2])
+            W[k + '.w2'], W[k + '.b2'] = f(hd.net[3].weight.reshape(-1)), f(hd.net[3].bias)
+        for k, m in (('pool.g', self.gmap_pooler), ('pool.v', self.vp_pooler), ('pool.t', self.txt_pooler)):
+            lin(k, m.dense)
+        lin('his.map', self.local_his_map); ln('his.ln', self.local_his_ln)
+        if not grad:
+            self._wcache = W
+        return W
+
+    # ---------------------------------------------------------------- building blocks
+    def _drop(self, x, p):
+        return nn.functional.dropout(x, p, True) if (self.training and p > 0) else x
+
+    def _dense_res_ln(self, W, k_lin, k_ln, h, res, eps):
+        """LayerNorm(dense(h) + res): BertSelfOutput / BertOutput (vilmodel.py:173-177, 213-217)."""
+        p = self.config.hidden_dropout_prob
+        if self.training and p > 0:
+            z = Fn.linear(h, W[k_lin + '.w'], W[k_lin + '.b'], out_f32=True)
+            return Fn.layernorm(self._drop(z, p), W[k_ln + '.g'], W[k_ln + '.b'], eps, residual=res)
+        z = Fn.linear(h, W[k_lin + '.w'], W[k_lin + '.b'], residual=res, out_f32=True)
+        return Fn.layernorm(z, W[k_ln + '.g'], W[k_ln + '.b'], eps, out_dtype=res.dtype)
+
+    def _bert_layer(self, W, key, x, nh, kmask, mode):  # vilmodel.py:226-232
+        H, eps = x.shape[-1], self.config.layer_norm_eps
+        qkv = Fn.linear(x, W[key + '.qkv.w'], W[key + '.qkv.b'])
+        a = Fn.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], nh, kmask, mode)
+        a = self._dense_res_ln(W, key + '.ao', key + '.aln', a, x, eps)
+        i = Fn.linear(a, W[key + '.ff1.w'], W[key + '.ff1.b'], act=ACT_GELU)
+        return self._dense_res_ln(W, key + '.ff2', key + '.fln', i, a, eps)
+
+    # ---------------------------------------------------------------- language (vilmodel.py:678-688)
+    def forward_text(self, txt_ids, txt_masks, act_txt=None, act_txt_masks=None, obj_txt=None, obj_txt_masks=None):
+        W, cfg, cd = self._weights(), self.config, self.compute_dtype
+        B, L = txt_ids.shape
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        pos = torch.arange(L, device=txt_ids.device, dtype=torch.int32).repeat(B)
+        x = Fn.embed_ln(B * L, H, cd, txt_ids.device, E1=W['emb.word'], idx1=_i32(txt_ids.reshape(-1)),
+                        E2=W['emb.pos'], idx2=pos, vec=W['emb.type'][0], lno=(W['emb.ln.g'], W['emb.ln.b']),
+                        eps=cfg.layer_norm_eps).view(B, L, H)
+        x = self._drop(x, cfg.hidden_dropout_prob)
+        tm = txt_masks.contiguous()
+        for i in range(cfg.num_l_layers):
+            x = self._bert_layer(W, 'lang.%d' % i, x, nh, tm, MASK_NEG10000)
+        if not getattr(cfg, 'update_lang_bert', True):
+            x = x.detach()
+        if obj_txt is None and not self.REVERIE:
+            return x
+        # IGL (vilmodel.py:521-528; REVERIE uses object words only, vilmodel_reverie.py:523-529)
+        obj = nn.functional.embedding(obj_txt, W['emb.obj'])
+        if self.REVERIE:
+            ctx, cm = obj, obj_txt_masks
+        else:
+            ctx = torch.cat([nn.functional.embedding(act_txt, W['emb.act']), obj], 1)
+            cm = torch.cat([act_txt_masks, obj_txt_masks], 1)
+        ctx = ctx.to(cd).contiguous()
+        q = Fn.linear(x, W['igl.q.w'], W['igl.q.b'])
+        kv = Fn.linear(ctx, W['igl.kv.w'], W['igl.kv.b'])
+        aug = Fn.attention(q, kv[..., :H], kv[..., H:], nh, cm.contiguous(), MASK_NEG10000)
+        return Fn.igl_blend(aug, x.contiguous(), W['igl.aug.w'], W['igl.aug.b'], W['igl.ori.w'], W['igl.ori.b'])
+
+    # ---------------------------------------------------------------- panorama
+    def _objv2_tokens(self, W, fts, lens, nav_types):
+        """ASV: object tokens -> self-encoder -> per-view mean [B*V,128] rows (vilmodel.py:697-714)."""
+        cfg, cd = self.config, self.compute_dtype
+        B, V, O, _ = fts.shape
+        d = cfg.obj_v2_size
+        fts = fts.float().contiguous()
+        e = Fn.embed_ln(B * V * O, d, cd, fts.device, feat=fts.view(B * V * O, -1)[:, :-1], Wf=W['obj.bbox.w'],
+                        bf=W['obj.bbox.b'], E1=W['obj.name'], idx1=_i32(fts[..., -1].reshape(-1)),
+                        E2=W['obj.nav'], idx2=_i32(nav_types.reshape(-1).repeat_interleave(O)),
+                        lno=(W['obj.ln.g'], W['obj.ln.b'])).view(B, V * O, d)
+        valid = (torch.arange(O, device=fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
+        for i in range(2):
+            e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
+        return e.reshape(B * V * O, d), O
+
+    def _pano_encoder(self, W, x, masks):
+        """2 pre-norm layers over packed-in_proj MHA with -inf key padding (transformer.py:170-182)."""
+        cfg = self.config
+        H, nh, p = cfg.hidden_size, cfg.num_attention_heads, cfg.hidden_dropout_prob
+        for i in range(cfg.num_pano_layers):
+            k = 'pano.%d' % i
+            y = Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5)
+            qkv = Fn.linear(y, W[k + '.qkv.w'], W[k + '.qkv.b'])
+            a = Fn.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], nh, masks, MASK_NEGINF)
+            if self.training and p > 0:
+                x = x + self._drop(Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b']), p)
+            else:
+                x = Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b'], residual=x)
+            y = Fn.layernorm(x, W[k + '.n2.g'], W[k + '.n2.b'], 1e-5)
+            hdn = self._drop(Fn.linear(y, W[k + '.ff1.w'], W[k + '.ff1.b'], act=ACT_GELU), p)
+            if self.training and p > 0:
+                x = x + self._drop(Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b']), p)
+            else:
+                x = Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b'], residual=x)
+        return x
+
+    def _pano_tokens(self, W, base, loc_fts, nav_types):
+        cfg = self.config
+        B, T, H = base.shape
+        x = Fn.embed_ln(B * T, H, self.compute_dtype, base.device, base=base.reshape(B * T, H),
+                        feat=loc_fts.float().reshape(B * T, -1).contiguous(), Wf=W['loc.w'], bf=W['loc.b'],
+                        lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=_i32(nav_types.reshape(-1)),
+                        vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b'])).view(B, T, H)
+        return self._drop(x, getattr(cfg, 'image_dropout_prob', cfg.hidden_dropout_prob) if self.REVERIE else cfg.hidden_dropout_prob)
+
+    def _concat2(self, a_fn, b_fn, B, V, ha, hb, device):
+        """[a | b] along the feature dim.  No-grad: both producers write straight into one buffer."""
+        if torch.is_grad_enabled():
+            return torch.cat([a_fn(None).view(B, V, ha), b_fn(None).view(B, V, hb)], -1)
+        cat = torch.empty(B, V, ha + hb, device=device, dtype=self.compute_dtype)
+        a_fn(cat[..., :ha]); b_fn(cat[..., ha:])
+        return cat
+
+    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
+        """R2R: vilmodel.py:690-742."""
+        W, cfg, cd = self._weights(), self.config, self.compute_dtype
+        B, V, _ = view_img_fts.shape
+        H, d = cfg.hidden_size, cfg.obj_v2_size
+        img = Fn.layernorm(Fn.linear(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], out_f32=True),
+                           W['img.ln.g'], W['img.ln.b'], 1e-12, out_dtype=cd)
+        obj_rows, O = self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types)
+        x = self._pano_tokens(W, img, loc_fts, nav_types)
+        pano_masks = torch.arange(V, device=x.device)[None] < view_lens[:, None]
+        x = self._pano_encoder(W, x, pano_masks.contiguous())
+        g, b = W['pano.norm.g'], W['pano.norm.b']
+        cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
+                            lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
+                            B, V, H, d, x.device)
+        pano = Fn.layernorm(Fn.linear(cat, W['visobj.lin.w'], W['visobj.lin.b'], out_f32=True),
+                            W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out_dtype=cd)
+        fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'])
+        return pano, pano_masks, fused
+
+    # ---------------------------------------------------------------- navigation (vilmodel.py:745-830)
+    def _text_kv(self, W, txt_embeds):
+        """All 16 text K/V projections of the 8 x-layers as one GEMM.  Cached per txt_embeds tensor in
+        no-grad mode (the text is constant for a whole episode, agent.py:420 vs :471)."""
+        if not torch.is_grad_enabled():
+            key = (txt_embeds.data_ptr(), txt_embeds._version, tuple(txt_embeds.shape), txt_embeds.dtype)
+            if self._kv_cache is not None and self._kv_cache[0] == key:
+                return self._kv_cache[1]
+        kv = Fn.linear(txt_embeds, W['x.txtkv.w'], W['x.txtkv.b'])
+        if not torch.is_grad_enabled():
+            self._kv_cache = (key, kv, txt_embeds)      # keep txt_embeds alive so the pointer stays unique
+        return kv
+
+    @staticmethod
+    def fusion_indices(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, Vp, skip=2):
+        """Host-side viewpoint-id matching of the logit-fusion loop (vilmodel.py:790-805) -> index arrays.
+        gmap_src[b,j]: local slot to add to node j (>=0), -2 = add the back-track sum, -1 = nothing.
+        bw_mask[b,k]: local slot k is a candidate that is an already-visited node."""
+        B = len(gmap_vpids)
+        vis_np = gmap_visited_masks.cpu().numpy() if isinstance(gmap_visited_masks, torch.Tensor) else np.asarray(gmap_visited_masks)
+        src = np.full((B, G), -1, np.int32)
+        bw = np.zeros((B, Vp), np.uint8)
+        for i in range(B):
+            names = gmap_vpids[i]
+            visited = {vp for vp, m in zip(names, vis_np[i]) if m}
+            slot = {}
+            for j, c in enumerate(vp_cand_vpids[i]):
+                if j >= skip:
+                    if c in visited:
+                        bw[i, j] = 1
+                    else:
+                        slot[c] = j
+            for j, vp in enumerate(names):
+                if j >= skip and vp not in visited:
+                    src[i, j] = slot.get(vp, -2)
+        return src, bw
+
+    def _x_layers(self, W, kv, txt_masks, feats, masks, dists):
+        """Global and local CrossmodalEncoders in lock-step: every GEMM is one grouped launch over both
+        branches (vilmodel.py:540-549, 454-469)."""
+        cfg = self.config
+        H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
+        brs = ('g', 'l')
+        sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
+        for i in range(nl):
+            ks = ['x.%s.%d' % (b, i) for b in brs]
+            q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(2)])
+            a = []
+            for j in range(2):
+                off = ((j * nl + i) * 2) * H
+                a.append(Fn.attention(q[j], kv[..., off:off + H], kv[..., off + H:off + 2 * H], nh, txt_masks, MASK_NEG10000))
+            feats = self._grouped_res_ln(W, ks, '.co', '.cln', a, feats, eps)
+            qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(2)])
+            a = [Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, masks[j], MASK_NEG10000,
+                              dists if j == 0 else None, sw if j == 0 else None, sb if j == 0 else None) for j in range(2)]
+            feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
+            inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(2)], act=ACT_GELU)
+            feats = self._grouped_res_ln(W, ks, '.ff2', '.fln', inter, feats, eps)
+        return feats
+
+    def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
+        p = self.config.hidden_dropout_prob
+        if self.training and p > 0:
+            z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], None) for j in range(2)], out_f32=True)
+            return [Fn.layernorm(self._drop(z[j], p), W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, residual=res[j]) for j in range(2)]
+        z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], res[j]) for j in range(2)], out_f32=True)
+        return [Fn.layernorm(z[j], W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, out_dtype=res[j].dtype) for j in range(2)]
+
+    def _heads(self, W, items):
+        """items: list of (key, x [..,K]) -> raw scores; first layers grouped in one launch (vilmodel.py:616-628)."""
+        h = Fn.linear_grouped([(x, W[k + '.l1.w'], W[k + '.l1.b'], None) for k, x in items], act=ACT_RELU, out_f32=True)
+        return [Fn.head_tail(h[j], W[k + '.ln.g'], W[k + '.ln.b'], W[k + '.w2'], W[k + '.b2']) for j, (k, _) in enumerate(items)]
+
+    def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
+                                    gmap_masks, gmap_pair_dists, gmap_visited_masks, gmap_vpids,
+                                    vp_img_embeds, vp_pos_fts, vp_masks, vp_nav_masks, vp_obj_masks, vp_cand_vpids,
+                                    gmap_src=None, bw_mask=None):
+        W, cfg, cd = self._weights(), self.config, self.compute_dtype
+        B, G, H = gmap_img_embeds.shape
+        Vp = vp_img_embeds.shape[1]
+        dev = gmap_img_embeds.device
+        txt = txt_embeds.to(cd)
+        txt = txt if txt.is_contiguous() else txt.contiguous()
+        tm = txt_masks.contiguous()
+        g = Fn.embed_ln(B * G, H, cd, dev, base=gmap_img_embeds.to(cd).reshape(B * G, H),
+                        feat=gmap_pos_fts.float().reshape(B * G, -1).contiguous(), Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'],
+                        lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']), E1=W['gmap.step'],
+                        idx1=_i32(gmap_step_ids.reshape(-1))).view(B, G, H)
+        v = Fn.embed_ln(B * Vp, H, cd, dev, base=vp_img_embeds.to(cd).reshape(B * Vp, H),
+                        feat=vp_pos_fts.float().reshape(B * Vp, -1).contiguous(), Wf=W['vp.pos.w'], bf=W['vp.pos.b'],
+                        lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)
+        dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
+        kv = self._text_kv(W, txt)
+        g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
+
+        items = [('head.g', g), ('head.l', v)]
+        if self.sap_fuse_linear is not None:
+            items.append(('head.f', torch.cat([g[:, 0], v[:, 0]], 1)))
+        if vp_obj_masks is not None:
+            items.append(('head.o', v))
+        sc = self._heads(W, items)
+        fuse_raw = sc[2] if self.sap_fuse_linear is not None else None
+        if gmap_src is None:
+            src_np, bw_np = self.fusion_indices(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, Vp, 2)
+            gmap_src, bw_mask = torch.from_numpy(src_np).to(dev), torch.from_numpy(bw_np).to(dev)
+        gl, ll, fl = Fn.nav_logits(sc[0], sc[1], fuse_raw, gmap_masks.contiguous(), gmap_visited_masks.contiguous(),
+                                   vp_nav_masks.contiguous(), gmap_src, bw_mask)
+        obj_logits = None
+        if vp_obj_masks is not None:
+            obj_logits = sc[-1].masked_fill(vp_obj_masks.logical_not(), -float('inf'))
+
+        # RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN
+        rows = [g[:, 0], v[:, 0], txt[:, 0]]
+        keys = ['pool.g', 'pool.v', 'pool.t']
+        if torch.is_grad_enabled():
+            pooled = torch.cat(Fn.linear_grouped([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], act=ACT_TANH), -1)
+        else:
+            pooled = torch.empty(B, 3 * H, device=dev, dtype=cd)
+            K.gemm([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], ACT_TANH,
+                   outs=[pooled[:, j * H:(j + 1) * H] for j in range(3)])
+        cls = Fn.layernorm(Fn.linear(pooled, W['his.map.w'], W['his.map.b'], out_f32=True), W['his.ln.g'], W['his.ln.b'],
+                           cfg.layer_norm_eps, out_dtype=cd)
+        return {'gmap_embeds': g, 'vp_embeds': v, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fl,
+                'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls}
+
+    # ---------------------------------------------------------------- dispatch (vilmodel.py:838-858)
+    def forward(self, mode, batch, **kwargs):
+        if mode == 'language':
+            return self.forward_text(batch['txt_ids'], batch['txt_masks'], batch['act_txt_ids'], batch['act_txt_masks'],
+                                     batch['obj_txt_ids'], batch['obj_txt_masks'])
+        elif mode == 'panorama':
+            return self.forward_panorama_per_step(batch['view_img_fts'], batch['obj_img_fts'], batch['loc_fts'],
+                                                  batch['nav_types'], batch['view_lens'], batch['obj_lens'])
+        elif mode == 'navigation':
+            get = batch.get if hasattr(batch, 'get') else (lambda k, d=None: batch[k])
+            return self.forward_navigation_per_step(
+                batch['txt_embeds'], batch['txt_masks'], batch['gmap_img_embeds'], batch['gmap_step_ids'],
+                batch['gmap_pos_fts'], batch['gmap_masks'], batch['gmap_pair_dists'], batch['gmap_visited_masks'],
+                batch['gmap_vpids'], batch['vp_img_embeds'], batch['vp_pos_fts'], batch['vp_masks'],
+                batch['vp_nav_masks'], batch['vp_obj_masks'], batch['vp_cand_vpids'],
+                gmap_src=get('gmap_src'), bw_mask=get('bw_mask'))

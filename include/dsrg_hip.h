@@ -1,0 +1,136 @@
+/* dsrg_hip.h — C-ABI of libdsrg_hip.so, the MI355X (gfx950) kernel library under the DSRG
+ * navigation-policy network.
+ *
+ * The reference (CrystalSixone/DSRG) has no native boundary on this path: every op below is a
+ * torch.nn call inside finetune_src/models/vilmodel.py (FT/) or pretrain_src/model/ (PT/).  Each entry
+ * point cites the reference lines whose arithmetic it replaces.  Conventions:
+ *   - every function returns 0 on success, a negative DSRG_E* code on failure; dsrg_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers unless the parameter comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; the call only enqueues work on it;
+ *   - no entry point allocates, frees or synchronises; they are safe under hipGraph capture;
+ *   - `dtype` is DSRG_F32 or DSRG_BF16 and names the storage type of activations and weights;
+ *     biases, LayerNorm affine parameters, masks-derived terms and all statistics are fp32;
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef DSRG_HIP_H
+#define DSRG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSRG_ABI_VERSION 1
+
+enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
+enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
+
+int dsrg_abi_version(void);
+const char* dsrg_last_error(void);
+
+/* ---- GEMM: C = act(A · Wᵀ + bias) [+ residual] ------------------------------------------------
+ * Replaces every nn.Linear on the path (FT/vilmodel.py:111-113,169,195,209,338-340,555,577,622;
+ * FT/transformer.py:138-142 in_proj/out_proj/linear1/linear2; PT/pretrain_cmt.py:16-19,30-33;
+ * PT/vilmodel.py BertLMPredictionHead decoder).  A is [M,K] (lda), W is [N,K] (ldw, nn.Linear layout),
+ * bias is fp32 [N] or NULL, residual is [M,N] (ldr, storage dtype `dtype`) or NULL and is added
+ * AFTER the activation, C is [M,N] (ldc) stored as `out_dtype`.
+ * Up to DSRG_MAX_GROUPS independent problems run in one launch (grouped GEMM: the global- and
+ * local-branch x-layers, the three RMF poolers, the SAP heads).
+ * Requirements: K % 64 == 0 (bf16) / K % 32 == 0 (f32); A, W 16-byte aligned, lda/ldw multiples of
+ * 8 (bf16) / 4 (f32).  M, N arbitrary. */
+enum { DSRG_ACT_NONE = 0, DSRG_ACT_GELU = 1, DSRG_ACT_RELU = 2, DSRG_ACT_TANH = 3 };
+#define DSRG_MAX_GROUPS 8
+typedef struct {
+  const void* A; const void* W; const float* bias; const void* residual; void* C;
+  int32_t M, N, K;
+  int32_t lda, ldw, ldr, ldc;
+} dsrg_gemm_problem_t;
+int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
+                 int act, void* stream);
+
+/* ---- fused short-sequence attention ------------------------------------------------------------
+ * O[b,q,h,:] = softmax_k( scale·Q[b,q,h,:]·K[b,k,h,:] + mask_term(b,k) + sprel(b,q,k) ) · V[b,k,h,:]
+ * Replaces BertSelfAttention / BertOutAttention (FT/vilmodel.py:125-164, 349-376) and the
+ * nn.MultiheadAttention core of the pano encoder (FT/transformer.py:176-177).  Head dim is 64.
+ * Q/K/V/O are addressed as base + b*?_bs + row*?_rs + h*64 (+d), strides in elements, so packed
+ * QKV projections and hoisted text K/V panels are read in place.
+ * kmask: uint8 [B,Nk] (torch.bool) or NULL.  mask_mode:
+ *   DSRG_MASK_NONE; DSRG_MASK_NEG10000: + (1-m)·(-10000)  (FT/ops.py:24-33);
+ *   DSRG_MASK_NEGINF: -inf where !m (key_padding_mask, FT/vilmodel.py:727);
+ *   DSRG_MASK_PLUS1: + m·1.0 — the object self-encoder quirk, a bool mask ADDED to the scores
+ *   (FT/vilmodel.py:711-712 -> :143).
+ * pair_dists: fp32 [B,Nq,Nk] or NULL; sprel_w/sprel_b: device pointers to the two scalars of
+ * sprel_linear; the bias w·d+b (FT/vilmodel.py:757-759, 462-463) is formed in the kernel. */
+enum { DSRG_MASK_NONE = 0, DSRG_MASK_NEG10000 = 1, DSRG_MASK_NEGINF = 2, DSRG_MASK_PLUS1 = 3 };
+int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                       const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
+                       const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                       const float* sprel_w, const float* sprel_b,
+                       int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream);
+
+/* ---- LayerNorm over the last dim (wave reduction, fp32 statistics) -------------------------------
+ * out = LN(x [+ residual]) * gamma + beta.  Replaces BertLayerNorm / nn.LayerNorm
+ * (FT/vilmodel.py:73,170,176,210,216; FT/transformer.py:144-145,174,179; FT/ops.py:19).
+ * x is `in_dtype` (fp32 pre-LN sums written by dsrg_gemm_nt, or storage dtype), residual is
+ * `out_dtype` or NULL, H <= 1024 and H % 64 == 0. */
+int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma,
+                       const float* beta, void* out, int ldo, int M, int H, float eps, int in_dtype,
+                       int out_dtype, void* stream);
+
+/* ---- token embedding: sum of parts + LayerNorm ---------------------------------------------------
+ * out[r,:] = LNo( base[r,:] + LNf( Wf·feat[r,:] + bf ) + E1[idx1[r],:] + E2[idx2[r],:] + vec[:] )
+ * Every term is optional (NULL).  One kernel covers:
+ *   text embeddings (word + position + token-type -> LN), FT/vilmodel.py:76-91;
+ *   ASV object tokens (bbox linear + name embedding + nav-type embedding -> LN(128)), :698-708;
+ *   panorama tokens (img + LN(loc_linear) + nav_type + token_type[1] -> LN), :719-723;
+ *   graph-map tokens (img + step embedding + LN(Linear(7))), :753-755;
+ *   viewpoint tokens (img + LN(Linear(14))), :769.
+ * feat is fp32 [M,F] (ldf), F <= 16; Wf is fp32 [H,F]; E1/E2/vec/gammas/betas fp32; base/out `dtype`.
+ * lnf_* NULL => no LayerNorm on the feature term; lno_* NULL => no output LayerNorm. */
+int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, int ldf, int F, const float* Wf,
+                      const float* bf, const float* lnf_gamma, const float* lnf_beta,
+                      const float* E1, const int32_t* idx1, const float* E2, const int32_t* idx2,
+                      const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                      void* out, int ldo, int M, int H, int dtype, void* stream);
+
+/* ---- mean over groups of G consecutive rows: out[m,:] = mean_g x[m*G+g,:] -------------------------
+ * The per-view mean over ASV object tokens, padded slots included (FT/vilmodel.py:714). */
+int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, int M, int G, int H, int dtype,
+                        void* stream);
+
+/* ---- GAA: global adaptive aggregation of the panorama ---------------------------------------------
+ * a[b,v] = softmax_v( tanh( x[b,v,:]·w + bias ) ) over ALL V slots (unmasked);
+ * out[b,:] = sum_v a[b,v]·x[b,v,:].  FT/vilmodel.py:735-740 (REVERIE vilmodel_reverie.py:753-758).
+ * x is [B,V,H] contiguous in `dtype`, w fp32 [H], bias fp32 [1], out [B,H] `dtype`; V <= 64. */
+int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* out, int B, int V,
+                      int H, int dtype, void* stream);
+
+/* ---- ClsPrediction tail: score[r] = LN(h[r,:])·w2 + b2 ---------------------------------------------
+ * h = relu(Linear(x)) comes from dsrg_gemm_nt (fp32, DSRG_ACT_RELU).  FT/vilmodel.py:616-628
+ * (net.2 LayerNorm eps 1e-12, net.3 Linear(H,1)).  h fp32 [M,H] (ldh); score fp32 [M]. */
+int dsrg_head_tail_fwd(const float* h, int ldh, const float* gamma, const float* beta, const float* w2,
+                       const float* b2, float eps, float* score, int M, int H, void* stream);
+
+/* ---- navigation logits: dynamic fusion + masking + global/local logit fusion ------------------------
+ * fw = sigmoid(fuse_raw[b]);  gl = g_raw*fw, ll = l_raw*(1-fw);  -inf masking
+ * (FT/vilmodel.py:773-785), then fused = gl; fused[:,0] += ll[:,0]; for each real, unvisited graph
+ * node j: += ll[cand slot of j] if j is a current candidate else += sum of ll over candidates that are
+ * visited nodes (FT/vilmodel.py:788-805; pre-training variant PT/pretrain_cmt.py:269-285).
+ * The viewpoint-id string matching of the reference is done once on the host and arrives as
+ *   gmap_src int32 [B,G]: k >= 0 -> add ll[b,k];  -2 -> add the back-track sum;  -1 -> add nothing;
+ *   bw_mask uint8 [B,Vp]: 1 where local token k is a candidate that is an already-visited node.
+ * fuse_raw may be NULL (fw = 0.5).  Masks are torch.bool (uint8).  All logits fp32. */
+int dsrg_nav_logits_fwd(const float* g_raw, const float* l_raw, const float* fuse_raw,
+                        const uint8_t* gmap_masks, const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
+                        const int32_t* gmap_src, const uint8_t* bw_mask, float* global_logits,
+                        float* local_logits, float* fused_logits, int B, int G, int Vp, void* stream);
+
+/* ---- IGL gate: w = sigmoid(aug·wa + ba + x·wo + bo); out = w·aug + (1-w)·x --------------------------
+ * FT/vilmodel.py:525-528.  aug/x/out [M,H] `dtype`; wa/wo fp32 [H]; ba/bo fp32 [1]. */
+int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo,
+                       const float* bo, void* out, int M, int H, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSRG_HIP_H */

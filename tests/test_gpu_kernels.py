@@ -1,0 +1,185 @@
+"""gpu: each libdsrg_hip.so entry point against a plain torch fp32 restatement of the same op,
+called through the C-ABI (dsrg_amd.kernels -> ctypes).  fp32 storage must agree to ~1e-5 relative
+(exact-fp32 MFMA, different summation order); bf16 storage to bf16 rounding of the result."""
+import math
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from dsrg_amd import kernels
+    return kernels
+
+
+def _r(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+ACTS = {0: lambda z: z, 1: torch.nn.functional.gelu, 2: torch.relu, 3: torch.tanh}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K_,act,res,of32', [
+    (2432, 768, 768, 0, True, True), (1280, 2304, 768, 0, False, False), (2304, 3072, 768, 1, False, False),
+    (2304, 768, 3072, 0, True, False), (64, 768, 2304, 0, False, True), (6912, 384, 128, 0, False, False),
+    (100, 1000, 768, 0, False, True), (37, 30522, 768, 0, False, True), (1, 768, 1536, 2, False, True),
+    (513, 130, 896, 3, False, False),
+])
+def test_gemm(K, dtype, M, N, K_, act, res, of32):
+    x, w, b = _r(M, K_, dtype=dtype), _r(N, K_, seed=1, scale=0.05, dtype=dtype), _r(N, seed=2)
+    r = _r(M, N, seed=3, dtype=dtype) if res else None
+    out = K.gemm([(x, w, b, r)], act, of32)[0]
+    ref = ACTS[act](x.float() @ w.float().T + b)
+    if res:
+        ref = ref + r.float()
+    assert out.dtype == (torch.float32 if of32 else dtype)
+    tol = 2e-5 * math.sqrt(K_) if dtype == torch.float32 else (1e-3 * math.sqrt(K_) / 16 if of32 else 3e-2)
+    err = (out.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * max(1.0, scale), (err, tol, scale)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_grouped_strided(K, dtype):
+    """two branches in one launch; strided A (row 0 of each sequence) and strided C (concat buffer)."""
+    B, G, Vp, H = 16, 20, 38, 768
+    g, v = _r(B, G, H, dtype=dtype), _r(B, Vp, H, seed=1, dtype=dtype)
+    w1, w2 = _r(H, H, seed=2, scale=0.05, dtype=dtype), _r(H, H, seed=3, scale=0.05, dtype=dtype)
+    b1, b2 = _r(H, seed=4), _r(H, seed=5)
+    o = K.gemm([(g, w1, b1, None), (v, w2, b2, None)])
+    for out, x, w, b in ((o[0], g, w1, b1), (o[1], v, w2, b2)):
+        ref = x.float() @ w.float().T + b
+        assert (out.float() - ref).abs().max().item() <= (1e-3 if dtype == torch.float32 else 8e-2)
+    cat = torch.zeros(B, 2 * H, device='cuda', dtype=dtype)
+    K.gemm([(g[:, 0], w1, b1, None), (v[:, 0], w2, b2, None)], 3, outs=[cat[:, :H], cat[:, H:]])
+    ref = torch.cat([torch.tanh(g[:, 0].float() @ w1.float().T + b1), torch.tanh(v[:, 0].float() @ w2.float().T + b2)], 1)
+    assert (cat.float() - ref).abs().max().item() <= (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def _attn_ref(q, k, v, nh, kmask, mode, dists, sw, sb, scale=0.125):
+    B, Nq, _ = q.shape
+    sp = lambda t: t.float().reshape(B, t.shape[1], nh, 64).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(k).transpose(-1, -2) * scale
+    if mode == 1:
+        s = s + (1.0 - kmask[:, None, None].float()) * -10000.0
+    elif mode == 2:
+        s = s.masked_fill(~kmask[:, None, None], float('-inf'))
+    elif mode == 3:
+        s = s + kmask[:, None, None].float()
+    if dists is not None:
+        s = s + (dists * sw + sb)[:, None]
+    return (torch.softmax(s, -1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, Nq, nh * 64)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [
+    (8, 12, 20, 80, 1, False), (8, 12, 38, 38, 1, False), (8, 12, 20, 20, 1, True), (4, 12, 36, 36, 2, False),
+    (4, 2, 108, 108, 3, False), (2, 2, 720, 720, 3, False), (2, 12, 100, 250, 1, False), (3, 12, 1, 5, 0, False),
+])
+def test_attention(K, dtype, B, nh, Nq, Nk, mode, sprel):
+    H = nh * 64
+    self_att = Nq == Nk
+    if self_att:      # packed QKV, read in place through strides
+        qkv = _r(B, Nq, 3 * H, dtype=dtype)
+        q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
+    else:
+        q, kv = _r(B, Nq, H, dtype=dtype), _r(B, Nk, 2 * H, seed=1, dtype=dtype)
+        k, v = kv[..., :H], kv[..., H:]
+    lens = torch.randint(1, Nk + 1, (B,), generator=torch.Generator().manual_seed(5)); lens[0] = Nk
+    kmask = (torch.arange(Nk)[None] < lens[:, None]).cuda() if mode else None
+    dists = (_r(B, Nq, Nk, seed=7).abs() * 5) if sprel else None
+    sw, sb = (torch.tensor([-0.21]).cuda(), torch.tensor([0.07]).cuda()) if sprel else (None, None)
+    out = K.attention(q, k, v, nh, kmask, mode, dists, sw, sb)
+    ref = _attn_ref(q, k, v, nh, kmask, mode, dists, sw, sb)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= (2e-5 if dtype == torch.float32 else 2e-2), err
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('H', [768, 128])
+def test_layernorm_and_embed(K, dtype, H):
+    M = 777
+    x, res = _r(M, H), _r(M, H, seed=1, dtype=dtype)
+    g, b = 1 + 0.1 * _r(H, seed=2), 0.1 * _r(H, seed=3)
+    out = K.layernorm(x, g, b, 1e-12, res, dtype)
+    ref = torch.nn.functional.layer_norm(x + res.float(), (H,), g, b, 1e-12)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert (out.float() - ref).abs().max().item() <= tol
+    # token embedding: base + LN(feat linear) + two gathers + vec -> LN
+    F_ = 7
+    feat8 = _r(M, F_ + 1, seed=4)
+    Wf, bf = _r(H, F_, seed=5, scale=0.3), _r(H, seed=6, scale=0.02)
+    E1, E2, vec = _r(45, H, seed=7), _r(3, H, seed=8), _r(H, seed=9)
+    i1 = torch.randint(0, 45, (M,), dtype=torch.int32).cuda(); i2 = torch.randint(0, 3, (M,), dtype=torch.int32).cuda()
+    base = _r(M, H, seed=10, dtype=dtype)
+    out = K.embed_ln(M, H, dtype, 'cuda', base=base, feat=feat8[:, :F_], Wf=Wf, bf=bf, lnf=(g, b), E1=E1, idx1=i1, E2=E2,
+                     idx2=i2, vec=vec, lno=(b + 1, g - 1), eps=1e-12)
+    t = torch.nn.functional.layer_norm(feat8[:, :F_] @ Wf.T + bf, (H,), g, b, 1e-12)
+    ref = torch.nn.functional.layer_norm(base.float() + t + E1[i1.long()] + E2[i2.long()] + vec, (H,), b + 1, g - 1, 1e-12)
+    assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 3e-2)
+    out = K.embed_ln(M, H, dtype, 'cuda', feat=feat8[:, :F_], Wf=Wf, bf=bf, E1=E1, idx1=i1)
+    ref = feat8[:, :F_] @ Wf.T + bf + E1[i1.long()]
+    assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pool_mean_head_blend(K, dtype):
+    B, V, H = 9, 36, 768
+    x = _r(B, V, H, dtype=dtype)
+    w, b = _r(H, scale=0.05, seed=1), _r(1, seed=2)
+    out = K.gaa_pool(x, w, b)
+    a = torch.softmax(torch.tanh(x.float() @ w + b), 1)
+    ref = (x.float() * a[..., None]).sum(1)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (out.float() - ref).abs().max().item() <= tol
+    rows = _r(B * V * 3, 128, dtype=dtype)
+    out = K.group_mean(rows, 3)
+    assert (out.float() - rows.float().reshape(-1, 3, 128).mean(1)).abs().max().item() <= tol
+    h = _r(B * V, H).relu()
+    g, be, w2, b2 = 1 + 0.1 * _r(H, seed=3), 0.1 * _r(H, seed=4), _r(H, seed=5, scale=0.05), _r(1, seed=6)
+    sc = K.head_tail(h, g, be, w2, b2)
+    ref = torch.nn.functional.layer_norm(h, (H,), g, be, 1e-12) @ w2 + b2
+    assert (sc - ref).abs().max().item() <= 2e-5
+    aug, xx = _r(50, H, dtype=dtype), _r(50, H, seed=1, dtype=dtype)
+    wa, ba, wo, bo = _r(H, scale=0.05, seed=7), _r(1, seed=8), _r(H, scale=0.05, seed=9), _r(1, seed=10)
+    out = K.igl_blend(aug, xx, wa, ba, wo, bo)
+    ww = torch.sigmoid(aug.float() @ wa + ba + xx.float() @ wo + bo)[:, None]
+    assert (out.float() - (ww * aug.float() + (1 - ww) * xx.float())).abs().max().item() <= tol * 4
+
+
+def test_nav_logits_vs_reference_loop(K):
+    """fusion kernel + host index builder against the reference's Python double loop semantics
+    (restated in oracle/dsrg_oracle.py: fuse_logits)."""
+    import numpy as np
+    from dsrg_amd import synth
+    from dsrg_amd.vilmodel import GlocalTextPathNavCMT as M
+    from oracle.dsrg_oracle import fuse_logits
+    B, G, Vp = 32, 20, 38
+    nb = synth.navigation_batch(B, G, Vp, seed=3)
+    g_raw, l_raw, f_raw = _r(B, G), _r(B, Vp, seed=1), _r(B, seed=2)
+    gm, gv, vn = (torch.from_numpy(nb[k]).cuda() for k in ('gmap_masks', 'gmap_visited_masks', 'vp_nav_masks'))
+    src, bw = M.fusion_indices(nb['gmap_vpids'], nb['gmap_visited_masks'], nb['vp_cand_vpids'], G, Vp)
+    gl, ll, fl = K.nav_logits(g_raw, l_raw, f_raw, gm, gv, vn, torch.from_numpy(src).cuda(), torch.from_numpy(bw).cuda())
+    fw = torch.sigmoid(f_raw)[:, None]
+    rgl = (g_raw * fw).masked_fill(gv | ~gm, float('-inf'))
+    rll = (l_raw * (1 - fw)).masked_fill(~vn, float('-inf'))
+    rfl = fuse_logits(rgl.cpu(), rll.cpu(), nb['gmap_vpids'], nb['gmap_visited_masks'], nb['vp_cand_vpids'], 2)
+    for a, r in ((gl, rgl), (ll, rll), (fl, rfl.cuda())):
+        fin = torch.isfinite(r)
+        assert (torch.isfinite(a) == fin).all()
+        assert (a[fin] - r[fin]).abs().max().item() <= 1e-6
+    assert (src == -2).any() and (src >= 0).any() and bw.any()
+
+
+def test_errors_are_loud(K):
+    from dsrg_amd._lib import DsrgHipError
+    x, w = _r(4, 100), _r(8, 100)
+    with pytest.raises(DsrgHipError):
+        K.gemm([(x, w, None, None)])            # K not a multiple of 32
+    with pytest.raises(DsrgHipError):
+        K.gemm([(x.cpu(), w.cpu(), None, None)])  # no CPU path

@@ -1,0 +1,82 @@
+"""gpu: the HIP-backed GlocalTextPathNavCMT against (a) the golden vectors produced by the reference's own
+model files and (b) the CPU oracle, on the 3-step recurrent chain language -> (panorama -> navigation)x3.
+
+fp32 mode: logits within 1e-3 max-abs (BASELINE north_star), identical argmax, -inf positions coincide.
+bf16 mode: stated tolerance 6e-2 max-abs on logits / embeddings 1.5e-1 (13 post-LN blocks in bf16 storage);
+argmax must agree wherever the reference's top-2 margin exceeds 2x the logit tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(tag, reverie, dtype):
+    from dsrg_amd.config import DSRGConfig
+    if reverie:
+        from dsrg_amd.vilmodel_reverie import GlocalTextPathNavCMT
+    else:
+        from dsrg_amd.vilmodel import GlocalTextPathNavCMT
+    sd = common.synth_sd(tag)
+    m = GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict={'bert.' + k if i % 2 else k: v for i, (k, v) in enumerate(sd.items())},
+                                             compute_dtype=dtype)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize('tag,reverie', [('r2r_c1', False), ('reverie_c3', True)])
+def test_fp32_matches_reference_golden(tag, reverie):
+    gold = common.load_gold(tag)
+    m = _model(tag, reverie, torch.float32)
+    with torch.no_grad():
+        out = common.run_chain(lambda mode, b: m(mode, b), gold['meta'], device='cuda')
+    errs = common.compare(out, gold, tol=1e-3, logit_tol=1e-3)
+    print(tag, 'fp32 max-abs', {k: '%.1e' % v for k, v in errs.items()})
+    for k in gold:
+        if k.endswith('_ck'):
+            assert abs(out[k][1] - gold[k][1]) <= 1e-5 * gold[k][1] + 1e-2, k
+
+
+@pytest.mark.parametrize('tag,reverie', [('r2r_c1', False), ('reverie_c3', True)])
+def test_bf16_within_stated_tolerance(tag, reverie):
+    gold = common.load_gold(tag)
+    m = _model(tag, reverie, torch.bfloat16)
+    with torch.no_grad():
+        out = common.run_chain(lambda mode, b: m(mode, b), gold['meta'], device='cuda')
+    errs = common.compare(out, gold, tol=1.5e-1, logit_tol=6e-2, check_argmax=False)
+    print(tag, 'bf16 max-abs', {k: '%.1e' % v for k, v in errs.items()})
+    for t in range(3):
+        f = gold['s%d_fused_logits' % t]
+        top2 = np.sort(np.where(np.isfinite(f), f, -1e30), 1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 0.12
+        assert (out['s%d_argmax' % t][clear] == gold['s%d_argmax' % t][clear]).all()
+
+
+def test_vlnbert_wrapper_and_kv_cache():
+    """VLNBert(args) drop-in: defaultdict batch handling, NotImplementedError on bad mode, text-K/V cache
+    gives the same result as a fresh computation, and a new txt_embeds tensor invalidates it."""
+    from types import SimpleNamespace
+    from dsrg_amd.model import VLNBert
+    from dsrg_amd import synth
+    args = SimpleNamespace(model='r2r', dataset='r2r', bert_ckpt_file=None, feat_dropout=0.4, fusion='dynamic', graph_sprels=True)
+    net = VLNBert(args, compute_dtype=torch.float32).cuda().eval()
+    with pytest.raises(NotImplementedError):
+        net('bogus', {})
+    B = 4
+    with torch.no_grad():
+        lb = common.to_t(synth.language_batch(B, 40, 7), 'cuda')
+        txt = net('language', lb)
+        nb = common.to_t(synth.navigation_batch(B, 12, 38, 7), 'cuda')
+        nb.update(txt_embeds=txt, txt_masks=lb['txt_masks'])
+        o1 = net('navigation', nb)
+        o2 = net('navigation', nb)          # served from the K/V cache
+        net.vln_bert.invalidate_caches()
+        o3 = net('navigation', nb)
+        assert torch.equal(o1['fused_logits'], o2['fused_logits']) and torch.equal(o1['fused_logits'], o3['fused_logits'])
+        txt2 = txt * 1.5
+        nb['txt_embeds'] = txt2
+        o4 = net('navigation', nb)
+        assert not torch.equal(o1['cls_embeds'], o4['cls_embeds'])
+    assert set(o1) == {'gmap_embeds', 'vp_embeds', 'global_logits', 'local_logits', 'fused_logits', 'obj_logits', 'txt_embeds', 'cls_embeds'}
+    assert o1['obj_logits'] is None
