@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — nav-policy forward steps/sec on MI355X (BASELINE.json metric, config[1]: R2R nav-step, bf16, bs=64).
+
+One step = one 'panorama' + one 'navigation' call on a batch of 64 episodes (synthetic R2R shapes: L=80, 36 views,
+3 objv2 objects/view, 20 graph nodes), inputs resident in HBM, RMF memory fed back step to step.  Every 15th step
+(max_action_len, a new episode batch) the instruction encoding changes and the hoisted text K/V panel is recomputed
+inside the timed region, as a rollout would.  N>1: one process per GPU (torchrun), independent replicas of 64
+episodes each (weak scaling, no data-path collective); value = N*64*K / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--dtype bf16|fp32] [--eager]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_BF16 = 2.5e15   # dense bf16 MFMA FLOP/s, MI355X (MI355X_MICROARCH.md "Chip-level parameters")
+MFMA_PEAK_F32 = 157.3e12
+EPISODE_LEN = 15          # max_action_len of the reference rollout (agent.py:434)
+
+CONFIGS = {   # name -> (reverie, B, L, G, O, No)
+    'c1': (False, 8, 80, 20, 3, 0),
+    'c2': (False, 64, 80, 20, 3, 0),
+    'c3': (True, 64, 80, 20, 3, 20),
+    'c5': (False, 64, 250, 100, 3, 0),
+}
+
+
+def T(b, dev):
+    return {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+
+
+def nav_step_flops(L, V, O, G, Vp, og=False, hoisted_kv=True):
+    """Algorithmic FLOPs of one episode-nav-step (SURVEY.md section 8d formula, 2*MAC)."""
+    H, d, FF = 768, 128, 3072
+    H2 = H * H
+
+    def xlayer(N):
+        f = 28 * N * H2 + 4 * N * L * H + 4 * N * N * H
+        return f if hoisted_kv else f + 4 * L * H2
+    nav = sum(4 * xlayer(N) for N in (G, Vp)) + 2 * (G + Vp + (Vp if og else 0)) * H2 + 4 * H2 + 6 * H2 + 6 * H2 \
+        + 2 * (7 * G + 14 * Vp) * H
+    n = V * O
+    T_ = Vp - 2
+    pano = 2 * V * H2 + 2 * (8 * n * d * d + 4 * n * d * FF + 4 * n * n * d) + 2 * (24 * T_ * H2 + 4 * T_ * T_ * H) + 2 * V * (H + d) * H
+    return nav + pano
+
+
+def build(cfg_name, dtype, dev):
+    from dsrg_amd import synth
+    from dsrg_amd.config import DSRGConfig
+    reverie, B, L, G, O, No = CONFIGS[cfg_name]
+    if reverie:
+        from dsrg_amd.vilmodel_reverie import GlocalTextPathNavCMT
+    else:
+        from dsrg_amd.vilmodel import GlocalTextPathNavCMT
+    cfg = DSRGConfig()
+    model = GlocalTextPathNavCMT(cfg, compute_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes).items()}
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    lbs = [synth.language_batch(B, L, 100 + e) for e in range(2)]
+    pb = synth.panorama_batch(B, 36, O, 100, reverie=reverie, No=No)
+    Vp = pb['nav_types'].shape[1] + 2
+    vlens = (36 + pb['obj_lens'] + 2) if reverie else None
+    nb = synth.navigation_batch(B, G, Vp, 100, ncand=pb['ncand'], nav_types=pb['nav_types'], vp_lens=vlens,
+                                reverie=reverie, all_valid=(cfg_name == 'c5'))
+    return model, cfg, sd, lbs, pb, nb, (reverie, B, L, G, O, No, Vp)
+
+
+def cpu_baseline(cfg, sd, lb, pb, nb, dims, budget_s=20.0):
+    """The CPU oracle (a restatement of the reference's PyTorch path, oracle/dsrg_oracle.py) timed on the host cores
+    on the same workload: bounded sample of nav-steps at the full batch size."""
+    from oracle import dsrg_oracle
+    reverie, B = dims[0], dims[1]
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    l = T(lb, 'cpu')
+    with torch.no_grad():
+        txt = dsrg_oracle.forward(sd, cfg, 'language', l, reverie)
+        p, n = T(pb, 'cpu'), T(nb, 'cpu')
+        n.update(txt_embeds=txt, txt_masks=l['txt_masks'])
+
+        def step():
+            pe, pm, pf = dsrg_oracle.forward(sd, cfg, 'panorama', p, reverie)
+            n['vp_img_embeds'] = torch.cat([torch.zeros_like(pe[:, :2]), pe], 1)
+            n['gmap_img_embeds'][:, 2] = pf
+            return dsrg_oracle.forward(sd, cfg, 'navigation', n, reverie)
+        step()
+        t0, it = time.perf_counter(), 0
+        while it < 3 or (time.perf_counter() - t0 < budget_s and it < 20):
+            step()
+            it += 1
+        dt = time.perf_counter() - t0
+    return {'value': B * it / dt, 'unit': 'episode-nav-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full nav-steps (panorama+navigation, B=%d, fp32, torch %s CPU, %d threads), %.1f s'
+                      % (it, B, torch.__version__, cores, dt)}
+
+
+def gemm_roofline(model, runner, dtype):
+    """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step, then re-issue
+    each launch `rep` times back to back between HIP events on the launch stream; achieved = algorithmic FLOPs of the
+    launches of the dominant tile variant / their measured time."""
+    from dsrg_amd import kernels
+    kernels.GEMM_TRACE = []
+    with torch.no_grad():
+        runner._body()
+    trace, kernels.GEMM_TRACE = kernels.GEMM_TRACE, None
+    torch.cuda.synchronize()
+    rep = 20
+    by_tile = {}
+    for rec in trace:
+        kernels.gemm_replay(rec)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rep):
+            kernels.gemm_replay(rec)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / rep
+        d = by_tile.setdefault(rec['tile'], {'flops': 0.0, 'time': 0.0, 'launches': 0})
+        d['flops'] += rec['flops']; d['time'] += t; d['launches'] += 1
+    dom = max(by_tile, key=lambda k: by_tile[k]['time'])
+    d = by_tile[dom]
+    peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
+    tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
+    return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
+            'frac': d['flops'] / d['time'] / peak, 'traffic': None,
+            'kernel': 'gemm_nt_kernel<%s,%dx%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', dom[0], dom[1]),
+            'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
+            'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
+            'all_gemm_us_per_step': tot_t * 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=150)
+    ap.add_argument('--warmup', type=int, default=15)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--eager', action='store_true', help='launch kernels from Python each step instead of replaying a HIP graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the DSRG hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+
+    from dsrg_amd.runner import GraphedNavStep
+    model, cfg, sd, lbs, pb, nb, dims = build(a.config, dtype, dev)
+    reverie, B, L, G, O, No, Vp = dims
+    with torch.no_grad():
+        txts = []
+        for lb in lbs:
+            l = T(lb, dev)
+            txts.append((model('language', l), l['txt_masks']))
+    runner = GraphedNavStep(model, txts[0][0], txts[0][1], T(pb, dev), T(nb, dev), use_graph=not a.eager, reverie=reverie)
+
+    def run(nsteps, start):
+        for s in range(start, start + nsteps):
+            if s % EPISODE_LEN == 0:
+                runner.set_text(*txts[(s // EPISODE_LEN) % 2])
+            runner.step()
+
+    run(a.warmup, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps, a.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fused = runner.out['fused_logits']
+    assert torch.isfinite(fused).any(1).all(), 'bench produced no finite logits'
+
+    if rank == 0:
+        fl = nav_step_flops(L, 36, O, G, Vp, og=reverie, hoisted_kv=True) + 4 * L * 768 * 768 * 8 / EPISODE_LEN
+        out = {
+            'metric': 'nav-policy forward steps/sec (R2R shapes, bs=64) + % bf16 MFMA peak on GEMMs',
+            'value': world * B * a.steps / dt, 'unit': 'episode-nav-steps/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config[1]: R2R nav-step inference (panorama + navigation), %s' % a.dtype
+                       if a.config == 'c2' else 'config %s' % a.config,
+                       'name': a.config, 'episodes_per_gpu': B, 'txt_len': L, 'views': 36, 'objv2_per_view': O,
+                       'graph_nodes': G, 'vp_tokens': Vp, 'reverie': reverie, 'launch': 'eager' if a.eager else 'hipgraph',
+                       'text_kv': 'hoisted: one GEMM per episode batch (every %d steps), inside the timed region' % EPISODE_LEN,
+                       'parallelism': 'replicas x%d (episode batch sharding, no collective)' % world},
+            'algorithmic_gflop_per_episode_step': fl / 1e9,
+            'whole_step_tflops': world * B * a.steps * fl / dt / 1e12,
+            'whole_step_frac_of_mfma_peak': B * a.steps * fl / dt / (MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32),
+        }
+        if not a.no_roofline:
+            out['roofline'] = gemm_roofline(model, runner, dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, sd, lbs[0], pb, nb, dims)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -24,6 +24,7 @@ SIGNATURES = {
     'dsrg_abi_version': (C.c_int, []),
     'dsrg_last_error': (C.c_char_p, []),
     'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
+    'dsrg_gemm_nt_plan': (C.c_int, [C.POINTER(GemmProblem), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dsrg_attention_fwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _P, _P,
                                      _I, _I, _I, _I, _F, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),

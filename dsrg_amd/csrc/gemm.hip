@@ -182,23 +182,32 @@ int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   return DSRG_OK;
 }
 
-template <typename T, typename OutT>
-int dispatch_tile(GemmArgs& a, hipStream_t s) {
-  // tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
-  auto count = [&](int bm, int bn) {
+// tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
+int plan_tiles(GemmArgs& a, int& bm, int& bn) {
+  auto count = [&](int m, int n) {
     int tot = 0;
     for (int i = 0; i < a.nprob; ++i) {
       a.tile_start[i] = tot;
-      tot += ((a.p[i].M + bm - 1) / bm) * ((a.p[i].N + bn - 1) / bn);
+      tot += ((a.p[i].M + m - 1) / m) * ((a.p[i].N + n - 1) / n);
     }
     a.tile_start[a.nprob] = tot;
     return tot;
   };
   int maxM = 0;
   for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
-  if (maxM > 64 && count(128, 128) >= 400) return launch<T, OutT, 128, 128>(a, count(128, 128), s);
-  if (maxM > 64 && count(64, 128) >= 128) return launch<T, OutT, 64, 128>(a, count(64, 128), s);
-  return launch<T, OutT, 64, 64>(a, count(64, 64), s);
+  if (maxM > 64 && count(128, 128) >= 400) { bm = 128; bn = 128; }
+  else if (maxM > 64 && count(64, 128) >= 128) { bm = 64; bn = 128; }
+  else { bm = 64; bn = 64; }
+  return count(bm, bn);
+}
+
+template <typename T, typename OutT>
+int dispatch_tile(GemmArgs& a, hipStream_t s) {
+  int bm, bn;
+  const int tiles = plan_tiles(a, bm, bn);
+  if (bm == 128) return launch<T, OutT, 128, 128>(a, tiles, s);
+  if (bn == 128) return launch<T, OutT, 64, 128>(a, tiles, s);
+  return launch<T, OutT, 64, 64>(a, tiles, s);
 }
 
 }  // namespace
@@ -237,4 +246,16 @@ extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, 
     return dispatch_tile<bf16_t, bf16_t>(a, s);
   }
   return dispatch_tile<float, float>(a, s);
+}
+
+extern "C" int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int* bm, int* bn, int* ntiles) {
+  DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS && bm && bn && ntiles, "dsrg_gemm_nt_plan: bad arguments");
+  (void)dtype;
+  GemmArgs a;
+  a.nprob = 0;
+  for (int i = 0; i < nproblems; ++i)
+    if (problems[i].M > 0 && problems[i].N > 0) a.p[a.nprob++] = problems[i];
+  *bm = *bn = *ntiles = 0;
+  if (a.nprob) *ntiles = plan_tiles(a, *bm, *bn);
+  return DSRG_OK;
 }

@@ -87,7 +87,21 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None):
         res.append(out)
     odt = F32 if out_f32 else dt
     _lib.check(lib.dsrg_gemm_nt(arr, n, dt, odt, act, _stream()), 'dsrg_gemm_nt')
+    if GEMM_TRACE is not None:
+        bm, bn, nt = C.c_int(), C.c_int(), C.c_int()
+        lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt))
+        keep = [t for p in problems for t in p if t is not None] + res
+        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value),
+                           'wgs': nt.value, 'flops': sum(2.0 * a.M * a.N * a.K for a in arr), 'keep': keep})
     return res
+
+
+GEMM_TRACE = None   # bench.py sets this to a list to record the GEMM launches of one step
+
+
+def gemm_replay(rec):
+    """Re-issue a recorded dsrg_gemm_nt launch (same pointers; outputs are overwritten with the same values)."""
+    _lib.check(_lib.load().dsrg_gemm_nt(rec['arr'], rec['n'], rec['dt'], rec['odt'], rec['act'], _stream()), 'dsrg_gemm_nt')
 
 
 def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125):

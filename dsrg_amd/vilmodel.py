@@ -445,6 +445,14 @@ class GlocalTextPathNavCMT(nn.Module):
             self._kv_cache = (key, kv, txt_embeds)      # keep txt_embeds alive so the pointer stays unique
         return kv
 
+    def text_kv(self, txt_embeds, out=None):
+        """[B,L,16*768] panel of the text keys/values of all x-layers (both branches), uncached."""
+        W = self._weights()
+        txt = txt_embeds.to(self.compute_dtype).contiguous()
+        if out is None:
+            return Fn.linear(txt, W['x.txtkv.w'], W['x.txtkv.b'])
+        return K.gemm([(txt, W['x.txtkv.w'], W['x.txtkv.b'], None)], outs=[out])[0]
+
     @staticmethod
     def fusion_indices(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, Vp, skip=2):
         """Host-side viewpoint-id matching of the logit-fusion loop (vilmodel.py:790-805) -> index arrays.
@@ -508,7 +516,10 @@ class GlocalTextPathNavCMT(nn.Module):
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
                                     gmap_masks, gmap_pair_dists, gmap_visited_masks, gmap_vpids,
                                     vp_img_embeds, vp_pos_fts, vp_masks, vp_nav_masks, vp_obj_masks, vp_cand_vpids,
-                                    gmap_src=None, bw_mask=None):
+                                    gmap_src=None, bw_mask=None, txt_kv=None):
+        """Extension keys (optional, not in the reference): `gmap_src`/`bw_mask` = precomputed fusion_indices()
+        on the device, `txt_kv` = precomputed text_kv(txt_embeds); with them the call does no host work and
+        can be captured in a HIP graph (dsrg_amd.runner)."""
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, G, H = gmap_img_embeds.shape
         Vp = vp_img_embeds.shape[1]
@@ -524,7 +535,7 @@ class GlocalTextPathNavCMT(nn.Module):
                         feat=vp_pos_fts.float().reshape(B * Vp, -1).contiguous(), Wf=W['vp.pos.w'], bf=W['vp.pos.b'],
                         lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
-        kv = self._text_kv(W, txt)
+        kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
         g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
 
         items = [('head.g', g), ('head.l', v)]
@@ -572,4 +583,4 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch['gmap_pos_fts'], batch['gmap_masks'], batch['gmap_pair_dists'], batch['gmap_visited_masks'],
                 batch['gmap_vpids'], batch['vp_img_embeds'], batch['vp_pos_fts'], batch['vp_masks'],
                 batch['vp_nav_masks'], batch['vp_obj_masks'], batch['vp_cand_vpids'],
-                gmap_src=get('gmap_src'), bw_mask=get('bw_mask'))
+                gmap_src=get('gmap_src'), bw_mask=get('bw_mask'), txt_kv=get('txt_kv'))

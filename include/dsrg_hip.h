@@ -47,6 +47,10 @@ typedef struct {
 } dsrg_gemm_problem_t;
 int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
                  int act, void* stream);
+/* Which block tile (bm x bn) and how many workgroups dsrg_gemm_nt would use for these problems (host-only
+ * query, no launch; used by bench.py to attribute measured durations to a kernel variant). */
+int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int* bm, int* bn,
+                      int* ntiles);
 
 /* ---- fused short-sequence attention ------------------------------------------------------------
  * O[b,q,h,:] = softmax_k( scale·Q[b,q,h,:]·K[b,k,h,:] + mask_term(b,k) + sprel(b,q,k) ) · V[b,k,h,:]
