@@ -112,6 +112,175 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA attention.  One workgroup per (episode, head, 64-query group); wave w owns the 16-query
+// tile w.  Keys are processed in chunks of 128 with an online softmax, K staged row-major (128-B rows,
+// same XOR swizzle as the GEMM), V staged TRANSPOSED (Vt[d][key], 272-B rows: conflict-free ds_read_b64).
+//   S^T tile  = K · Q^T   (v_mfma_f32_16x16x32_bf16, A = K rows, B = Q rows): lane (c = lane&15, g = lane>>4)
+//               holds S[query c][key 16t + 4g + r], r = 0..3  -> the softmax max/sum over keys is in-lane
+//               plus two xor-shuffles (16, 32).
+//   O^T      += V^T · P^T with P taken STRAIGHT from those accumulators as the B operand: k-slot 8g+e of the
+//               MFMA is key 16*t0+4g+e (e<4) / 16*t1+4g+e-4 (e>=4) of a tile pair (t0,t1); the V^T fragment
+//               is read with the same key permutation (two ds_read_b64 32 bytes apart).  No P round trip.
+//   lane ends with O[query c][d = 16*dt + 4g + 0..3]  -> 8-byte stores.
+constexpr int KC = 128, NKT = KC / 16, VRS = 272;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
+  __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
+  __shared__ float mt[KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const bool active = q0 < a.Nq;                               // wave-uniform
+  const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
+  const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + b * a.v_bs + h * DH;
+  bf16_t* Op = reinterpret_cast<bf16_t*>(a.O) + b * a.o_bs + h * DH;
+
+  const int qrow = q0 + c16;
+  uint4 qf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if (active && qrow < a.Nq) {
+    qf[0] = *reinterpret_cast<const uint4*>(Qp + (size_t)qrow * a.q_rs + g * 8);
+    qf[1] = *reinterpret_cast<const uint4*>(Qp + (size_t)qrow * a.q_rs + 32 + g * 8);
+  }
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+  const float* drow = a.dists ? a.dists + ((size_t)b * a.Nq + (qrow < a.Nq ? qrow : 0)) * a.Nk : nullptr;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < a.Nk; k0 += KC) {
+    __syncthreads();
+    const int nk = min(KC, a.Nk - k0);
+    const int ntile = ((nk + 31) / 32) * 2;                    // even number of 16-key tiles
+    // ---- stage K (row-major, swizzled) and V (transposed); rows >= nk are zero
+    {
+      const int r = tid >> 3, c = tid & 7;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = r + 32 * p;
+        if (row < ntile * 16) {
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (row < nk) v = *reinterpret_cast<const uint4*>(Kp + (size_t)(k0 + row) * a.k_rs + c * 8);
+          *reinterpret_cast<uint4*>(Ks + kswz(row, c)) = v;
+        }
+      }
+      const int key = tid & 127, dc0 = tid >> 7;
+      if (key < ntile * 16) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int dc = dc0 + 2 * p;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (key < nk) v = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + key) * a.v_rs + dc * 8);
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(Vt + (dc * 8 + j) * VRS + key * 2) = e[j];
+        }
+      }
+      if (tid < KC) {
+        float t = -INFINITY;
+        if (tid < nk) {
+          t = 0.f;
+          if (a.kmask) {
+            const bool mk = a.kmask[(size_t)b * a.Nk + k0 + tid] != 0;
+            if (a.mask_mode == DSRG_MASK_NEG10000) t = mk ? 0.f : -10000.0f;
+            else if (a.mask_mode == DSRG_MASK_NEGINF) t = mk ? 0.f : -INFINITY;
+            else if (a.mask_mode == DSRG_MASK_PLUS1) t = mk ? 1.0f : 0.f;
+          }
+        }
+        mt[tid] = t;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+
+    // ---- S^T tiles
+    f32x4 s[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < ntile) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kswz(t * 16 + c16, g + 4 * kk));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), s[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- scale + mask + sprel, running max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      if (t < ntile) {
+        const float4 mk = *reinterpret_cast<const float4*>(&mt[t * 16 + 4 * g]);
+        const float mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[t][r] * a.scale + mm[r];
+          if (drow) {
+            const int key = k0 + t * 16 + 4 * g + r;
+            if (key < a.Nk) v += drow[key] * sw + sb;
+          }
+          s[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_safe);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+      if (t < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[t][r] - m_safe);
+          s[t][r] = p;
+          psum += p;
+        }
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    // ---- O^T += V^T · P^T
+#pragma unroll
+    for (int j = 0; j < NKT / 2; ++j) {
+      if (2 * j < ntile) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const char* vp = Vt + (dt * 16 + c16) * VRS + (32 * j + 4 * g) * 2;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vp), v1 = *reinterpret_cast<const uint2*>(vp + 32);
+          const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (qrow < a.Nq) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      st4(Op + (size_t)qrow * a.o_rs + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
+  }
+}
+
 }  // namespace
 
 extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
@@ -135,6 +304,14 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
   AttnArgs a{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask, mask_mode,
              pair_dists, sprel_w, sprel_b, Nq, Nk, scale};
   dim3 grid((Nq + QPB - 1) / QPB, NH, B), block(256);
+  const bool mfma_ok = dtype == DSRG_BF16 && q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+                       v_bs % 8 == 0 && o_rs % 4 == 0 && o_bs % 4 == 0 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 &&
+                       ((uintptr_t)O & 7) == 0;
+  if (mfma_ok) {
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((Nq + 63) / 64, NH, B), block, 0, (hipStream_t)stream, a);
+    DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
+    return DSRG_OK;
+  }
   if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
