@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdsrg_hip.so')
+LIB_PATH = os.environ.get('DSRG_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdsrg_hip.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3

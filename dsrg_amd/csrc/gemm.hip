@@ -8,6 +8,10 @@
 // Operands are passed to the MFMA swapped (W as the A operand, the activations as B) so that each
 // lane's 4 accumulator registers are 4 CONSECUTIVE output columns n of one row m: the epilogue then
 // reads bias/residual and writes C with 8/16-byte vector accesses.
+#include <stdlib.h>
+#ifndef DSRG_ABLATE
+#define DSRG_ABLATE 0   // diagnostic builds: 1 = no LDS-DMA in the K loop, 2 = no fragment reads / MFMA
+#endif
 #include "common.h"
 
 namespace {
@@ -32,7 +36,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <typename T, typename OutT, int BM, int BN>
+template <typename T, typename OutT, int BM, int BN, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
@@ -41,8 +45,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   constexpr int TILE_BYTES = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // ---- which problem / tile
-  int bid = blockIdx.x;
+  // ---- which problem / tile.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
+  // the hardware block id is first remapped to give every XCD one CONTIGUOUS run of logical tile ids (bijective
+  // for any grid size), and logical ids walk the tile grid in super-rows of GM M-tiles with N fastest-but-one:
+  // the ~32 tiles an XCD runs at a time then form a compact GM x (32/GM) patch that shares A and W panels in L2.
+  int bid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
@@ -50,8 +62,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   const dsrg_gemm_problem_t& P = args.p[g];
   const int M = P.M, N = P.N, K = P.K;
   const int t = bid - args.tile_start[g];
-  const int tiles_m = (M + BM - 1) / BM;
-  const int tm = t % tiles_m, tn = t / tiles_m;   // consecutive blocks share the W panel
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  constexpr int GM = 4;
+  const int per_group = GM * tiles_n;
+  const int grp = t / per_group, in_grp = t - grp * per_group;
+  const int gm = min(GM, tiles_m - grp * GM);          // rows in this (possibly short) super-row
+  const int tm = grp * GM + in_grp % gm, tn = in_grp / gm;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x;
@@ -62,32 +78,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   const T* __restrict__ A = reinterpret_cast<const T*>(P.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(P.W);
 
-  // ---- staging map: thread -> (row lr + 32*pass, 16B chunk lc)
-  const int lr = tid >> 3, lc = tid & 7;
-  constexpr int PA = BM / 32, PW = BN / 32;
-  uint4 ra[PA], rw[PW];
-
-  auto gload = [&](int k0) {
+  // ---- staging: LDS-DMA (global_load_lds_dwordx4), NST-deep ring, counted vmcnt.
+  // One wave-instruction moves 8 tile rows (64 lanes x 16 B = 1 KiB, lane-linear in LDS); the XOR swizzle is
+  // applied to the per-lane SOURCE chunk, the LDS image stays linear (row*128 + pos*16), and the fragment reads
+  // use the same involution.  Rows past M / N are clamped to the last valid row (their results are never stored).
+  constexpr int TR = BM + BN;           // tile rows per stage (A rows then W rows)
+  constexpr int LPS = TR / 32;          // LDS-DMA instructions per wave per stage
+  const T* src[LPS];
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      int m = m0 + lr + 32 * p;
-      ra[p] = (m < M) ? *reinterpret_cast<const uint4*>(A + (size_t)m * P.lda + k0 + lc * PER16)
-                      : make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < LPS; ++i) {
+    const int rb = i * 4 + wave;                       // 8-row block of the stage
+    const int row = rb * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (rb * 8 < BM) {
+      const int m = min(m0 + row, M - 1);
+      src[i] = A + (size_t)m * P.lda + chunk * PER16;
+    } else {
+      const int n = min(n0 + row - BM, N - 1);
+      src[i] = W + (size_t)n * P.ldw + chunk * PER16;
     }
+  }
+  // The DMA is issued from inline asm on purpose: hipcc does not count asm memory operations, so it cannot
+  // drain the ring with a vmcnt(0) in front of the fragment reads (it does for the builtin form); completion is
+  // tracked by the counted s_waitcnt below.  M0 (LDS destination base) is written in the statement that uses it.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto issue = [&](int stage, int k0) {
 #pragma unroll
-    for (int p = 0; p < PW; ++p) {
-      int n = n0 + lr + 32 * p;
-      rw[p] = (n < N) ? *reinterpret_cast<const uint4*>(W + (size_t)n * P.ldw + k0 + lc * PER16)
-                      : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < LPS; ++i) {
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * TILE_BYTES + (i * 4 + wave) * 1024);
+      const T* g = src[i] + k0;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
     }
-  };
-  auto lstore = [&](int buf) {
-    char* sa = smem + buf * TILE_BYTES;
-    char* sw = sa + BM * ROWB;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) *reinterpret_cast<uint4*>(sa + swz(lr + 32 * p, lc)) = ra[p];
-#pragma unroll
-    for (int p = 0; p < PW; ++p) *reinterpret_cast<uint4*>(sw + swz(lr + 32 * p, lc)) = rw[p];
   };
 
   f32x4 acc[MT][NT];
@@ -97,15 +120,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
+  constexpr int D = NST - 1;                 // prefetch distance in K-steps
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nk) issue(d, d * BK);
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    // stage kt has landed once all but the DMAs of the (up to D-1) younger stages are done
+    // (wait + barrier in one statement with a memory clobber: no LDS access may move across it)
+    const int younger = min(D - 1, nk - 1 - kt);
+    if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // everyone's stage-kt DMAs landed and everyone is done reading stage kt-1: refill that buffer
+#if DSRG_ABLATE != 1
+    if (kt + D < nk) issue(cur == 0 ? NST - 1 : cur - 1, (kt + D) * BK);
+#endif
     const char* sa = smem + cur * TILE_BYTES;
     const char* sw = sa + BM * ROWB;
+#if DSRG_ABLATE != 2
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int chunk = q + 4 * kk;
@@ -131,42 +164,61 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
           }
         }
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
+#endif
+    cur = cur == NST - 1 ? 0 : cur + 1;
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3]
+  // ---- epilogue.  A lane holds C[m][n..n+3] for 16 different rows per store, i.e. 32/64-byte row pieces: written
+  // straight to HBM that pattern, not the K loop, bounds these mid-size GEMMs.  The raw accumulators therefore go
+  // through LDS (fp32 [BM][BN] image over the drained ring, 16-B chunk index XOR (row & 7): conflict-free both ways)
+  // and leave as whole rows: 32 consecutive lanes cover BN consecutive columns (256 B bf16 / 512 B f32 per row),
+  // with bias, activation and the residual (read with the same coalescing) applied on the way out.
   const float* __restrict__ bias = P.bias;
-  const T* __restrict__ R = reinterpret_cast<const T*>(P.residual);
+  const T* __restrict__ Rp = reinterpret_cast<const T*>(P.residual);
   OutT* __restrict__ C = reinterpret_cast<OutT*>(P.C);
   const int act = args.act;
-  const bool vec_ok = ((P.ldc & 3) == 0) && (R == nullptr || (P.ldr & 3) == 0);
+  constexpr int CPR = BN / 4;                       // 16-B chunks per image row
+  float* cimg = reinterpret_cast<float*>(smem);
+  __syncthreads();                                  // every wave is done reading the last stage
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * WM + i * 16 + r16;
-    if (m >= M) continue;
+    const int row = wm * WM + i * 16 + r16;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * WN + j * 16 + q * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (n + 3 < N && vec_ok) {
-        if (bias) {
-          float4 b = *reinterpret_cast<const float4*>(bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
+      const int chunk = (wn * WN + j * 16) / 4 + q;
+      *reinterpret_cast<f32x4*>(cimg + row * BN + ((chunk ^ (row & 7)) << 2)) = acc[i][j];
+    }
+  }
+  __syncthreads();
+  const int oc = tid % CPR, orow0 = tid / CPR;      // this thread's chunk (fixed) and first row
+  constexpr int RPP = 256 / CPR;                    // rows per pass
+  const int n = n0 + oc * 4;
+  if (n < N) {
+    const bool vec = (n + 3 < N) && ((P.ldc & 3) == 0) && (Rp == nullptr || (P.ldr & 3) == 0);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
-        if (R) {
-          float4 r = ld4(R + (size_t)m * P.ldr + n);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) bv[e] = bias[n + e];
+    }
+#pragma unroll 4
+    for (int r = orow0; r < BM; r += RPP) {
+      const int m = m0 + r;
+      if (m >= M) break;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((oc ^ (r & 7)) << 2));
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(a4[e] + bv[e], act);
+      if (vec) {
+        if (Rp) {
+          const float4 rr = ld4(Rp + (size_t)m * P.ldr + n);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
         }
         st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
       } else {
         for (int e = 0; e < 4 && n + e < N; ++e) {
-          float x = v[e] + (bias ? bias[n + e] : 0.f);
-          x = apply_act(x, act);
-          if (R) x += Elem<T>::ld(R + (size_t)m * P.ldr + n + e);
+          float x = v[e];
+          if (Rp) x += Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
           Elem<OutT>::st(C + (size_t)m * P.ldc + n + e, x);
         }
       }
@@ -174,13 +226,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   }
 }
 
-template <typename T, typename OutT, int BM, int BN>
+template <typename T, typename OutT, int BM, int BN, int NST>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
-  constexpr int smem = 2 * (BM + BN) * ROWB;
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN>), dim3(total_tiles), dim3(256), smem, s, a);
+  constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
+  constexpr int smem = ring > cimg ? ring : cimg;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, BM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST>), dim3(total_tiles), dim3(256), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
   return DSRG_OK;
 }
+
+int g_nst_override = 0;
 
 // tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
 int plan_tiles(GemmArgs& a, int& bm, int& bn) {
@@ -195,8 +255,16 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn) {
   };
   int maxM = 0;
   for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
-  if (maxM > 64 && count(128, 128) >= 400) { bm = 128; bn = 128; }
-  else if (maxM > 64 && count(64, 128) >= 128) { bm = 64; bn = 128; }
+  static const char* force = getenv("DSRG_GEMM_TILE");     // tuning aid: "128x128" | "64x128" | "64x64"
+  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))
+    return count(bm, bn);
+  // Measured on MI355X (tools/bench_gemm.py): with a 2-deep ring every tile keeps >= 2 workgroups per CU, and the
+  // mid-size GEMMs of a nav-step (174..1400 tiles) are bound by per-workgroup latency, not by the MFMA rate, so the
+  // smallest tile that still gives >= 2 workgroups per CU wins; 128x128 only pays on >= ~4 rounds of tiles.
+  int minK = 1 << 30;
+  for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
+  if (maxM > 64 && minK >= 512 && count(128, 128) >= 1000) { bm = 128; bn = 128; }
+  else if (maxM > 64 && count(64, 128) >= 512) { bm = 64; bn = 128; }
   else { bm = 64; bn = 64; }
   return count(bm, bn);
 }
@@ -205,9 +273,17 @@ template <typename T, typename OutT>
 int dispatch_tile(GemmArgs& a, hipStream_t s) {
   int bm, bn;
   const int tiles = plan_tiles(a, bm, bn);
-  if (bm == 128) return launch<T, OutT, 128, 128>(a, tiles, s);
-  if (bn == 128) return launch<T, OutT, 64, 128>(a, tiles, s);
-  return launch<T, OutT, 64, 64>(a, tiles, s);
+  const int nst = g_nst_override;       // tuning aid only; the shipped ring depth is 2
+  if (bm == 128) {
+    if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
+    return launch<T, OutT, 128, 128, 2>(a, tiles, s);
+  }
+  if (bn == 128) {
+    if (nst == 3) return launch<T, OutT, 64, 128, 3>(a, tiles, s);
+    return launch<T, OutT, 64, 128, 2>(a, tiles, s);
+  }
+  if (nst == 3) return launch<T, OutT, 64, 64, 3>(a, tiles, s);
+  return launch<T, OutT, 64, 64, 2>(a, tiles, s);
 }
 
 }  // namespace

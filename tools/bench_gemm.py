@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of dsrg_gemm_nt on the nav-step's GEMM shapes (GPU box only).
+usage: python tools/bench_gemm.py            (env DSRG_GEMM_TILE=128x128|64x128|64x64 forces a tile)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dsrg_amd import kernels as K
+
+SHAPES = [  # name, [(M,N,K)...] grouped, act, out_f32, residual
+    ('x.cq/co/so  g+l N=768 K=768 f32out+res', [(1280, 768, 768), (2432, 768, 768)], 0, True, True),
+    ('x.qkv       g+l N=2304 K=768', [(1280, 2304, 768), (2432, 2304, 768)], 0, False, False),
+    ('x.ff1 gelu  g+l N=3072 K=768', [(1280, 3072, 768), (2432, 3072, 768)], 1, False, False),
+    ('x.ff2       g+l N=768 K=3072 f32out+res', [(1280, 768, 3072), (2432, 768, 3072)], 0, True, True),
+    ('pano.qkv    M=2304 N=2304 K=768', [(2304, 2304, 768)], 0, False, False),
+    ('pano.ff1    M=2304 N=3072 K=768', [(2304, 3072, 768)], 1, False, False),
+    ('pano.ff2    M=2304 N=768 K=3072 +res', [(2304, 768, 3072)], 0, False, True),
+    ('obj.ff1     M=6912 N=3072 K=128', [(6912, 3072, 128)], 1, False, False),
+    ('obj.ff2     M=6912 N=128 K=3072 f32out+res', [(6912, 128, 3072)], 0, True, True),
+    ('txtkv       M=5120 N=12288 K=768', [(5120, 12288, 768)], 0, False, False),
+    ('square 4096', [(4096, 4096, 4096)], 0, False, False),
+]
+
+def main():
+    dt = torch.bfloat16
+    for name, probs, act, of32, res in SHAPES:
+        ps = []
+        for (M, N, Kd) in probs:
+            x = (torch.rand(M, Kd, device='cuda') * 2 - 1).to(dt)
+            w = ((torch.rand(N, Kd, device='cuda') * 2 - 1) * 0.05).to(dt)
+            b = torch.rand(N, device='cuda')
+            r = (torch.rand(M, N, device='cuda') * 2 - 1).to(dt) if res else None
+            ps.append((x, w, b, r))
+        outs = K.gemm(ps, act, of32)
+        for _ in range(3):
+            K.gemm(ps, act, of32, outs=outs)
+        torch.cuda.synchronize()
+        # HIP-graph replay of `inner` back-to-back launches: no Python/ctypes time in the measurement
+        inner, rep = 20, 5
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            K.gemm(ps, act, of32, outs=outs)
+        torch.cuda.current_stream().wait_stream(st)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(inner):
+                K.gemm(ps, act, of32, outs=outs)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rep):
+            g.replay()
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (rep * inner)
+        fl = sum(2.0 * M * N * Kd for (M, N, Kd) in probs)
+        print('%-44s %8.1f us  %7.1f TFLOP/s' % (name, us, fl / us / 1e6), flush=True)
+
+if __name__ == '__main__':
+    main()
