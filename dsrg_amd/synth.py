@@ -195,3 +195,101 @@ def navigation_batch(B, G=20, Vp=38, seed=0, ncand=None, nav_types=None, vp_lens
         'vp_obj_masks': np.concatenate([zeros, zeros, nav_types == 2], 1) if reverie else None,
         'vp_cand_vpids': cand_vpids,
     }
+
+
+# --------------------------------------------------------------------------
+# pre-training trajectory batches (pretrain_src/data/tasks.py collators, dataset.py get_input)
+# --------------------------------------------------------------------------
+def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V=36, n_classes=1000):
+    """One collated batch for GlocalTextPathCMTPreTraining.forward(batch, task).
+    Trajectories of T_i steps; graph-map tokens [stop], visited (= trajectory viewpoints), unvisited (every
+    candidate ever seen that was never visited; some are seen from two steps, so the aggregation averages)."""
+    lb = language_batch(B, L, seed, min_len=min(12, L))
+    steps = integers('pt_steps', (B,), min_steps, max_steps + 1, seed)
+    S = int(steps.sum())
+    ncand_all = integers('pt_ncand', (S,), 3, 7, seed)
+    traj_vpids, traj_cand_vpids, gmap_vpids, gmap_visited, gmap_steps = [], [], [], [], []
+    s0 = 0
+    for i in range(B):
+        T = int(steps[i])
+        path = ['t%d_v%d' % (i, t) for t in range(T)]
+        cands_i, unv = [], []
+        for t in range(T):
+            nc = int(ncand_all[s0 + t])
+            c = []
+            if t + 1 < T:
+                c.append(path[t + 1])
+            if t > 0:
+                c.append(path[t - 1])
+                c.append('t%d_u%d_0' % (i, t - 1))        # seen again from this step -> averaged
+            k = 0
+            while len(c) < nc:
+                c.append('t%d_u%d_%d' % (i, t, k)); k += 1
+            order = np.argsort(uniform('pt_corder%d_%d' % (i, t), (len(c),), seed))
+            c = [c[j] for j in order]
+            cands_i.append(c)
+            for x in c:
+                if x not in path and x not in unv:
+                    unv.append(x)
+        s0 += T
+        traj_vpids.append(path)
+        traj_cand_vpids.append(cands_i)
+        gmap_vpids.append([None] + path + unv)
+        gmap_visited.append([0] + [1] * T + [0] * len(unv))
+        gmap_steps.append([0] + list(range(1, T + 1)) + [0] * len(unv))
+    glens = np.array([len(x) for x in gmap_vpids], np.int64)
+    G = int(glens.max())
+    pad = lambda rows, fill, dt: np.array([r + [fill] * (G - len(r)) for r in rows], dt)
+    gm = np.arange(G)[None] < glens[:, None]
+    d = uniform('pt_dist', (B, G, G), seed, 0.0, 10.0)
+    d = np.triu(d, 1); d = d + d.transpose(0, 2, 1)
+    real = gm.copy(); real[:, 0] = False
+    d = np.where(real[:, :, None] & real[:, None, :], d, 0.0).astype(np.float32)
+    # flattened per-step panoramas
+    nav_types = (np.arange(V)[None] < np.array([len(c) for cs in traj_cand_vpids for c in cs])[:, None]).astype(np.int64)
+    objv2, objv2_lens = _objv2('pt_objv2', S, V, O, seed)
+    loc = np.concatenate([_angle_feats('pt_loc', (S, V), seed), np.ones((S, V, 3), np.float32)], -1)
+    vp_pos = np.zeros((B, V + 1, 14), np.float32)
+    vp_pos[:, :, :7] = uniform('pt_vp_start', (B, 1, 7), seed)
+    last_nc = np.array([len(cs[-1]) for cs in traj_cand_vpids])
+    cm = (np.arange(V + 1)[None] >= 1) & (np.arange(V + 1)[None] < 1 + last_nc[:, None])
+    vp_pos[:, :, 7:] = np.where(cm[..., None], uniform('pt_vp_cand', (B, V + 1, 7), seed), 0.0)
+    batch = {
+        'txt_ids': lb['txt_ids'], 'txt_lens': lb['txt_lens'],
+        'traj_view_img_fts': uniform('pt_view', (S, V, 768), seed), 'traj_obj_img_fts': None,
+        'traj_loc_fts': loc, 'traj_nav_types': nav_types, 'traj_step_lens': [int(x) for x in steps],
+        'traj_vp_view_lens': np.full((S,), V, np.int64), 'traj_vp_obj_lens': None,
+        'traj_vpids': traj_vpids, 'traj_cand_vpids': traj_cand_vpids,
+        'traj_objv2_fts': objv2, 'traj_objv2_lens': objv2_lens,
+        'gmap_lens': glens, 'gmap_step_ids': pad(gmap_steps, 0, np.int64),
+        'gmap_pos_fts': np.where(gm[..., None], uniform('pt_gpos', (B, G, 7), seed), 0.0).astype(np.float32),
+        'gmap_pair_dists': d, 'gmap_vpids': gmap_vpids, 'vp_pos_fts': vp_pos,
+        'gmap_visited_masks': pad(gmap_visited, 0, np.int64).astype(bool),
+        'act_txt_ids': None, 'obj_txt_ids': None, 'act_lens': None, 'obj_lens': None,
+    }
+    if task.startswith('mlm'):
+        lab = np.full(lb['txt_ids'].shape, -1, np.int64)
+        pick = (uniform('pt_mlm_pick', lab.shape, seed, 0.0, 1.0) < 0.15) & lb['txt_masks']
+        pick[:, 0] = False
+        pick[:, 1] = True                                   # at least one masked token per row
+        lab[pick] = lb['txt_ids'][pick]
+        ids = lb['txt_ids'].copy(); ids[pick] = 103
+        batch['txt_ids'], batch['txt_labels'] = ids, lab
+    elif task.startswith('mrc'):
+        m = uniform('pt_mrc_pick', (B, V), seed, 0.0, 1.0) < 0.15
+        m[:, 0] = True
+        p = uniform('pt_mrc_probs', (B, V, n_classes), seed, 0.0, 1.0) ** 4
+        batch['vp_view_mrc_masks'] = m
+        batch['vp_view_probs'] = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+        batch['vp_obj_mrc_masks'], batch['vp_obj_probs'] = None, None
+    elif task.startswith('sap'):
+        # teacher action = a hashed unvisited candidate of the last step (global index) / its local slot, or stop
+        ga, la = np.zeros((B,), np.int64), np.zeros((B,), np.int64)
+        pickc = integers('pt_sap_pick', (B,), 0, 8, seed)
+        for i in range(B):
+            last = traj_cand_vpids[i][-1]
+            opts = [(gmap_vpids[i].index(c), j + 1) for j, c in enumerate(last) if c not in traj_vpids[i]]
+            if pickc[i] < 6 and opts:
+                ga[i], la[i] = opts[int(pickc[i]) % len(opts)]
+        batch['global_act_labels'], batch['local_act_labels'] = ga, la
+    return batch
