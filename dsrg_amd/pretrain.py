@@ -1,0 +1,275 @@
+"""MI355X-native pre-training model: drop-in for the reference's `GlocalTextPathCMTPreTraining`
+(pretrain_src/model/pretrain_cmt.py:38-392) over its backbone `GlocalTextPathCMT`
+(pretrain_src/model/vilmodel.py:716-840).
+
+Same constructor (a config with `pretrain_tasks`), same `forward(batch, task, compute_loss)` with task prefixes
+mlm / mrc / sap (+ `ValueError('invalid task')`), same per-sample un-reduced loss vectors, same `state_dict()` keys
+(624 tensors: `bert.*` backbone, `mlm_head.*` with the decoder tied to the word embeddings, `image_classifier.*`,
+`global_sap_head.*`, `local_sap_head.*`, `sap_fuse_linear.*`).  All arithmetic of the backbone and heads runs in the
+libdsrg_hip.so kernels through dsrg_amd.functional; only the final scalar losses (log-softmax / CE / KL on a few
+fp32 logits) are ATen.
+
+Two host-side loops of the reference become index tensors consumed on the device:
+  * `_aggregate_gmap_features` (vilmodel.py:597-635, dict-of-tensors pooling over the trajectory) -> one
+    gather + index_add with per-contribution weights (`gmap_aggregation_indices`);
+  * the SAP logit fusion (pretrain_cmt.py:269-285) -> `fusion_indices(skip=1)` + the nav_logits kernel.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as Fn
+from ._lib import ACT_GELU, ACT_RELU, MASK_NEG10000
+from .vilmodel import GlocalTextPathNavCMT as _Backbone, _cls_head, _dense_ln, _mod
+
+
+class GlocalTextPathCMT(_Backbone):
+    PRETRAIN = True
+
+    # ------------------------------------------------------------------ pieces
+    def _text(self, txt_ids, txt_lens):
+        L = txt_ids.shape[1]
+        txt_masks = torch.arange(L, device=txt_ids.device)[None] < txt_lens[:, None]
+        return self.forward_text(txt_ids, txt_masks), txt_masks
+
+    def _trajectory(self, b):
+        """ImageEmbeddings.forward over all steps of all trajectories at once (vilmodel.py:497-546): identical
+        arithmetic to the fine-tune panorama mode, so it IS that code path."""
+        pano, masks, fused = self.forward_panorama_per_step(
+            b['traj_view_img_fts'], b['traj_objv2_fts'], b['traj_loc_fts'], b['traj_nav_types'],
+            b['traj_vp_view_lens'], b['traj_objv2_lens'])
+        return pano, fused
+
+    @staticmethod
+    def gmap_aggregation_indices(traj_step_lens, traj_vpids, traj_cand_vpids, gmap_vpids, V, G):
+        """(dst, src, w): graph-map slot b*G+j  +=  w * row src of cat([pano.view(S*V,H), fused]).
+        Visited node = GAA-pooled panorama of (the last) step that stood on it; unvisited node = mean of every
+        candidate-view embedding that saw it before it was visited (vilmodel.py:605-627)."""
+        dst, src, w = [], [], []
+        S = int(sum(traj_step_lens))
+        s0 = 0
+        for i, T in enumerate(traj_step_lens):
+            vis, unv = {}, {}
+            for t in range(T):
+                vis[traj_vpids[i][t]] = S * V + s0 + t
+                for j, vp in enumerate(traj_cand_vpids[i][t]):
+                    if vp not in vis:
+                        unv.setdefault(vp, []).append((s0 + t) * V + j)
+            for j, vp in enumerate(gmap_vpids[i][1:], start=1):
+                if vp in vis:
+                    dst.append(i * G + j); src.append(vis[vp]); w.append(1.0)
+                else:
+                    for r in unv[vp]:
+                        dst.append(i * G + j); src.append(r); w.append(1.0 / len(unv[vp]))
+            s0 += T
+        return np.asarray(dst, np.int64), np.asarray(src, np.int64), np.asarray(w, np.float32)
+
+    def _gmap_input(self, W, pano, fused, b):
+        cfg, cd = self.config, self.compute_dtype
+        B, G = b['gmap_step_ids'].shape
+        S, V, H = pano.shape
+        dev = pano.device
+        dst, src, w = self.gmap_aggregation_indices(b['traj_step_lens'], b['traj_vpids'], b['traj_cand_vpids'], b['gmap_vpids'], V, G)
+        flat = torch.cat([pano.reshape(S * V, H), fused], 0)
+        rows = flat.index_select(0, torch.from_numpy(src).to(dev)).float() * torch.from_numpy(w).to(dev)[:, None]
+        img = torch.zeros(B * G, H, device=dev, dtype=torch.float32).index_add_(0, torch.from_numpy(dst).to(dev), rows).to(cd)
+        g = Fn.embed_ln(B * G, H, cd, dev, base=img, feat=b['gmap_pos_fts'].float().reshape(B * G, -1).contiguous(),
+                        Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'], lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']),
+                        E1=W['gmap.step'], idx1=b['gmap_step_ids'].reshape(-1).to(torch.int32).contiguous()).view(B, G, H)
+        gmask = (torch.arange(G, device=dev)[None] < b['gmap_lens'][:, None]).contiguous()
+        return g, gmask
+
+    def _vp_input(self, W, pano, b):
+        cfg, cd = self.config, self.compute_dtype
+        S, V, H = pano.shape
+        dev = pano.device
+        steps = torch.as_tensor(b['traj_step_lens'], device=dev)
+        last = torch.cumsum(steps, 0) - 1
+        B = last.shape[0]
+        T = b['vp_pos_fts'].shape[1]                 # = max(last view_len) + 1  ([stop] first)
+        vp_lens = b['traj_vp_view_lens'].index_select(0, last) + 1
+        img = torch.cat([torch.zeros(B, 1, H, device=dev, dtype=cd), pano.index_select(0, last)], 1)[:, :T].contiguous()
+        v = Fn.embed_ln(B * T, H, cd, dev, base=img.reshape(B * T, H), feat=b['vp_pos_fts'].float().reshape(B * T, -1).contiguous(),
+                        Wf=W['vp.pos.w'], bf=W['vp.pos.b'], lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, T, H)
+        vmask = (torch.arange(T, device=dev)[None] < vp_lens[:, None]).contiguous()
+        return v, vmask, last
+
+    # ------------------------------------------------------------------ vilmodel.py:730-779
+    def forward_backbone(self, b, return_gmap_embeds=True):
+        W = self._weights()
+        txt, tm = self._text(b['txt_ids'], b['txt_lens'])
+        pano, fused = self._trajectory(b)
+        kv = self.text_kv(txt) if not torch.is_grad_enabled() else Fn.linear(txt, W['x.txtkv.w'], W['x.txtkv.b'])
+        v, vmask, last = self._vp_input(W, pano, b)
+        tm = tm.contiguous()
+        if return_gmap_embeds:
+            g, gmask = self._gmap_input(W, pano, fused, b)
+            g, v = self._x_layers(W, kv, tm, [g, v], [gmask, vmask], b['gmap_pair_dists'].float().contiguous())
+            return g, v, last
+        (v,) = self._x_layers(W, kv, tm, [v], [vmask], None, brs=('l',))
+        return None, v, last
+
+    # ------------------------------------------------------------------ vilmodel.py:782-840
+    def forward_mlm(self, b):
+        """Text updated by the visual context: per x-layer, text queries attend over the (un-updated) graph-map /
+        viewpoint input tokens, then the text-side self-attention + FFN sub-layers; the two branches are summed."""
+        W, cfg = self._weights(), self.config
+        H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
+        txt, tm = self._text(b['txt_ids'], b['txt_lens'])
+        tm = tm.contiguous()
+        pano, fused = self._trajectory(b)
+        g, gmask = self._gmap_input(W, pano, fused, b)
+        v, vmask, _ = self._vp_input(W, pano, b)
+        ctx, cmask, brs = [g, v], [gmask, vmask], ('g', 'l')
+        t = [txt, txt]
+        for i in range(nl):
+            ks = ['x.%s.%d' % (br, i) for br in brs]
+            q = Fn.linear_grouped([(t[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(2)])
+            kv = Fn.linear_grouped([(ctx[j], W[ks[j] + '.ckv.w'], W[ks[j] + '.ckv.b'], None) for j in range(2)])
+            a = [Fn.attention(q[j], kv[j][..., :H], kv[j][..., H:], nh, cmask[j], MASK_NEG10000) for j in range(2)]
+            t = self._grouped_res_ln(W, ks, '.co', '.cln', a, t, eps)
+            qkv = Fn.linear_grouped([(t[j], W[ks[j] + '.lqkv.w'], W[ks[j] + '.lqkv.b'], None) for j in range(2)])
+            a = [Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, tm, MASK_NEG10000) for j in range(2)]
+            t = self._grouped_res_ln(W, ks, '.lso', '.lsln', a, t, eps)
+            inter = Fn.linear_grouped([(t[j], W[ks[j] + '.lff1.w'], W[ks[j] + '.lff1.b'], None) for j in range(2)], act=ACT_GELU)
+            t = self._grouped_res_ln(W, ks, '.lff2', '.lfln', inter, t, eps)
+        return t[0].float() + t[1].float()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('use GlocalTextPathCMTPreTraining.forward(batch, task) or forward_backbone / forward_mlm')
+
+    def _head_weights(self, W, lin, ln, f):      # heads live on the wrapper (pretrain_cmt.py:45-61)
+        pass
+
+
+def _region_head(h, n_out):   # RegionClassification, pretrain_cmt.py:12-23
+    return _cls_head(h, out=n_out)
+
+
+class GlocalTextPathCMTPreTraining(nn.Module):
+    def __init__(self, config, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = cfg = config
+        h = cfg.hidden_size
+        self.bert = GlocalTextPathCMT(cfg, compute_dtype=compute_dtype)
+        tasks = list(getattr(cfg, 'pretrain_tasks', ()))
+        if 'mlm' in tasks:
+            pred = _mod(transform=_dense_ln(h, h, cfg.layer_norm_eps), decoder=nn.Linear(h, cfg.vocab_size, bias=False))
+            pred.bias = nn.Parameter(torch.zeros(cfg.vocab_size))
+            self.mlm_head = _mod(predictions=pred)
+        if 'mrc' in tasks:
+            self.image_classifier = _region_head(h, cfg.image_prob_size)
+            op = getattr(cfg, 'obj_prob_size', 0)
+            self.obj_classifier = _region_head(h, op) if (op > 0 and op != cfg.image_prob_size) else None
+        if 'sap' in tasks:
+            self.global_sap_head, self.local_sap_head = _cls_head(h), _cls_head(h)
+            self.sap_fuse_linear = _cls_head(h, inp=2 * h) if cfg.glocal_fuse else None
+        if 'og' in tasks:
+            self.og_head = _cls_head(h)
+        for m in self.modules():
+            if m is not self.bert and not any(m is x for x in self.bert.modules()):
+                if isinstance(m, nn.Linear):
+                    nn.init.normal_(m.weight, 0.0, getattr(cfg, 'initializer_range', 0.02))
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+        self.tie_weights()
+
+    def tie_weights(self):   # pretrain_cmt.py:66-69
+        if hasattr(self, 'mlm_head'):
+            self.mlm_head.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None, **kw):
+        model = cls(config, **kw)
+        if state_dict:
+            own = model.state_dict()
+            model.load_state_dict({k: v for k, v in state_dict.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}, strict=False)
+        return model
+
+    # ------------------------------------------------------------------ heads
+    def _hw(self):
+        """compute-dtype views of the head weights (differentiable; small)."""
+        cd = self.bert.compute_dtype
+        W = {}
+        c = lambda t: t.to(cd).contiguous()
+        f = lambda t: t.float().contiguous()
+        lin = lambda k, m: W.update({k + '.w': c(m.weight), k + '.b': f(m.bias) if m.bias is not None else None})
+        ln = lambda k, m: W.update({k + '.g': f(m.weight), k + '.b': f(m.bias)})
+        for k in ('global_sap_head', 'local_sap_head', 'sap_fuse_linear', 'og_head', 'image_classifier', 'obj_classifier'):
+            hd = getattr(self, k, None)
+            if hd is not None:
+                self.bert._cls_head_weights(W, k, hd, lin, ln, f)
+        if hasattr(self, 'mlm_head'):
+            p = self.mlm_head.predictions
+            lin('mlm.t', p.transform.dense); ln('mlm.ln', p.transform.LayerNorm)
+            W['mlm.dec.w'], W['mlm.dec.b'] = c(p.decoder.weight), f(p.bias)
+        return W
+
+    def _scores(self, W, key, x):
+        """ClsPrediction -> [..] raw scores (Linear+ReLU in the GEMM epilogue, LN+Linear(H,1) tail kernel)."""
+        h = Fn.linear(x, W[key + '.l1.w'], W[key + '.l1.b'], act=ACT_RELU, out_f32=True)
+        return Fn.head_tail(h, W[key + '.ln.g'], W[key + '.ln.b'], W[key + '.w2'], W[key + '.b2'])
+
+    # ------------------------------------------------------------------ tasks
+    def forward(self, batch, task, compute_loss=True):
+        b = batch if hasattr(batch, 'get') else dict(batch)
+        if task.startswith('mlm'):
+            return self.forward_mlm(b, compute_loss)
+        elif task.startswith('mrc'):
+            return self.forward_mrc(b, compute_loss)
+        elif task.startswith('sap'):
+            return self.forward_sap(b, compute_loss)
+        raise ValueError('invalid task')
+
+    def forward_mlm(self, b, compute_loss=True):   # pretrain_cmt.py:142-167
+        W, cd = self._hw(), self.bert.compute_dtype
+        txt = self.bert.forward_mlm(b)
+        sel = b['txt_labels'] != -1
+        h = txt[sel].to(cd).contiguous()
+        h = Fn.linear(h, W['mlm.t.w'], W['mlm.t.b'], act=ACT_GELU, out_f32=True)
+        h = Fn.layernorm(h, W['mlm.ln.g'], W['mlm.ln.b'], self.config.layer_norm_eps, out_dtype=cd)
+        scores = Fn.linear(h, W['mlm.dec.w'], W['mlm.dec.b'], out_f32=True)
+        if compute_loss:
+            return F.cross_entropy(scores, b['txt_labels'][sel], reduction='none')
+        return scores
+
+    def forward_mrc(self, b, compute_loss=True):   # pretrain_cmt.py:175-228 (R2R: view regions only)
+        W, cd = self._hw(), self.bert.compute_dtype
+        _, v, last = self.bert.forward_backbone(b, return_gmap_embeds=False)
+        m = b['vp_view_mrc_masks']
+        T = m.shape[1]
+        lens = b['traj_vp_view_lens'].index_select(0, last)
+        ve = v[:, 1:1 + T]
+        if ve.shape[1] < T:
+            ve = F.pad(ve, (0, 0, 0, T - ve.shape[1]))
+        ve = ve * (torch.arange(T, device=v.device)[None] < lens[:, None])[..., None].to(ve.dtype)
+        x = ve[m].contiguous()
+        h = Fn.linear(x, W['image_classifier.l1.w'], W['image_classifier.l1.b'], act=ACT_RELU, out_f32=True)
+        h = Fn.layernorm(h, W['image_classifier.ln.g'], W['image_classifier.ln.b'], 1e-12, out_dtype=cd)
+        logits = Fn.linear(h, W['image_classifier.l2.w'], W['image_classifier.l2.b'], out_f32=True)
+        tgt = b['vp_view_probs'][m]
+        if not compute_loss:
+            return logits, tgt, None, None
+        return F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+
+    def forward_sap(self, b, compute_loss=True):   # pretrain_cmt.py:230-294
+        W = self._hw()
+        g, v, last = self.bert.forward_backbone(b)
+        B, G, _ = g.shape
+        T = v.shape[1]
+        dev = g.device
+        sg, sl = self._scores(W, 'global_sap_head', g), self._scores(W, 'local_sap_head', v)
+        fr = self._scores(W, 'sap_fuse_linear', torch.cat([g[:, 0], v[:, 0]], 1)) if self.sap_fuse_linear is not None else None
+        gmask = (torch.arange(G, device=dev)[None] < b['gmap_lens'][:, None]).contiguous()
+        nav_last = b['traj_nav_types'].index_select(0, last)                      # [B,V]
+        nav_ok = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), nav_last[:, :T - 1] == 1], 1).contiguous()
+        cands = [[None] + list(c[-1]) for c in b['traj_cand_vpids']]
+        src, bw = self.bert.fusion_indices(b['gmap_vpids'], b['gmap_visited_masks'], cands, G, T, skip=1)
+        gl, ll, fl = Fn.nav_logits(sg, sl, fr, gmask, b['gmap_visited_masks'].contiguous(), nav_ok,
+                                   torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev))
+        if not compute_loss:
+            return gl, ll, fl, b['global_act_labels'], b['local_act_labels']
+        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
+            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
+            + F.cross_entropy(fl, b['global_act_labels'], reduction='none')

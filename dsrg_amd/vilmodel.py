@@ -111,6 +111,7 @@ def _i32(t):
 
 class GlocalTextPathNavCMT(nn.Module):
     REVERIE = False
+    PRETRAIN = False        # pretrain_src/model/vilmodel.py:716-728 flavour: no IGL / heads / RMF, lang2visn sub-layers
     base_model_prefix = 'bert'
 
     def __init__(self, config, compute_dtype=torch.bfloat16):
@@ -129,10 +130,14 @@ class GlocalTextPathNavCMT(nn.Module):
 
         le = nn.Module()
         le.layer = nn.ModuleList([_bert_layer(h, cfg.intermediate_size, eps) for _ in range(cfg.num_l_layers)])
-        le.act_obj_token_emb = nn.Embedding(1 if self.REVERIE else 2, h)       # unused in forward
-        le.instr_actobj_encoder = _qkv(h)
-        le.instr_aug_linear, le.instr_ori_linear = nn.Linear(h, 1), nn.Linear(h, 1)
-        le.instr_fuse_layernorm = nn.LayerNorm(h, eps=eps)                      # unused in forward
+        if self.PRETRAIN:   # pretrain_src/model/vilmodel.py:688-690 (present in the state dict, unused in forward)
+            le.instr_act_encoder, le.instr_obj_encoder = _qkv(h), _qkv(h)
+            le.instr_fuse_layernorm = nn.LayerNorm(h, eps=1e-12)
+        else:
+            le.act_obj_token_emb = nn.Embedding(1 if self.REVERIE else 2, h)       # unused in forward
+            le.instr_actobj_encoder = _qkv(h)
+            le.instr_aug_linear, le.instr_ori_linear = nn.Linear(h, 1), nn.Linear(h, 1)
+            le.instr_fuse_layernorm = nn.LayerNorm(h, eps=eps)                      # unused in forward
         self.lang_encoder = le
 
         self.img_embeddings = _img_embeddings(cfg, self.REVERIE)
@@ -143,14 +148,15 @@ class GlocalTextPathNavCMT(nn.Module):
                   gmap_step_embeddings=nn.Embedding(cfg.max_action_steps, h), encoder=_x_encoder(cfg))
         ge.sprel_linear = nn.Linear(1, 1) if cfg.graph_sprels else None
         self.global_encoder = ge
-        self.global_sap_head, self.local_sap_head = _cls_head(h), _cls_head(h)
-        self.sap_fuse_linear = _cls_head(h, inp=2 * h) if cfg.glocal_fuse else None
-        if cfg.obj_feat_size > 0:
-            self.og_head = _cls_head(h)
-        # RMF (vilmodel.py:652-657)
-        self.gmap_pooler, self.vp_pooler, self.txt_pooler = (_mod(dense=nn.Linear(h, h)) for _ in range(3))
-        self.local_his_map = nn.Linear(3 * h, h)
-        self.local_his_ln = nn.LayerNorm(h, eps=eps)
+        if not self.PRETRAIN:
+            self.global_sap_head, self.local_sap_head = _cls_head(h), _cls_head(h)
+            self.sap_fuse_linear = _cls_head(h, inp=2 * h) if cfg.glocal_fuse else None
+            if cfg.obj_feat_size > 0:
+                self.og_head = _cls_head(h)
+            # RMF (vilmodel.py:652-657)
+            self.gmap_pooler, self.vp_pooler, self.txt_pooler = (_mod(dense=nn.Linear(h, h)) for _ in range(3))
+            self.local_his_map = nn.Linear(3 * h, h)
+            self.local_his_ln = nn.LayerNorm(h, eps=eps)
 
         self.init_weights()
         self._apply_freeze_flags()
@@ -185,7 +191,7 @@ class GlocalTextPathNavCMT(nn.Module):
             frz([self.embeddings, self.lang_encoder])
         if getattr(cfg, 'fix_pano_embedding', False) or getattr(cfg, 'fix_local_branch', False):
             frz([self.img_embeddings])
-        if getattr(cfg, 'fix_local_branch', False):
+        if getattr(cfg, 'fix_local_branch', False) and not self.PRETRAIN:
             frz([self.local_encoder, self.local_sap_head] + ([self.og_head] if hasattr(self, 'og_head') else []))
 
     @classmethod
@@ -248,10 +254,11 @@ class GlocalTextPathNavCMT(nn.Module):
         ln('emb.ln', e.LayerNorm)
         for i, L in enumerate(le.layer):
             bert_layer('lang.%d' % i, L)
-        lin('igl.q', le.instr_actobj_encoder.query)
-        packed('igl.kv', [le.instr_actobj_encoder.key, le.instr_actobj_encoder.value])
-        for k, m in (('igl.aug', le.instr_aug_linear), ('igl.ori', le.instr_ori_linear)):
-            W[k + '.w'], W[k + '.b'] = f(m.weight.reshape(-1)), f(m.bias)
+        if not self.PRETRAIN:
+            lin('igl.q', le.instr_actobj_encoder.query)
+            packed('igl.kv', [le.instr_actobj_encoder.key, le.instr_actobj_encoder.value])
+            for k, m in (('igl.aug', le.instr_aug_linear), ('igl.ori', le.instr_ori_linear)):
+                W[k + '.w'], W[k + '.b'] = f(m.weight.reshape(-1)), f(m.bias)
 
         lin('img.lin', ie.img_linear); ln('img.ln', ie.img_layer_norm)
         W['loc.w'], W['loc.b'] = f(ie.loc_linear.weight), f(ie.loc_linear.bias); ln('loc.ln', ie.loc_layer_norm)
@@ -291,21 +298,35 @@ class GlocalTextPathNavCMT(nn.Module):
                 packed(k + '.qkv', [L.visn_self_att.self.query, L.visn_self_att.self.key, L.visn_self_att.self.value])
                 lin(k + '.so', L.visn_self_att.output.dense); ln(k + '.sln', L.visn_self_att.output.LayerNorm)
                 lin(k + '.ff1', L.visn_inter.dense); lin(k + '.ff2', L.visn_output.dense); ln(k + '.fln', L.visn_output.LayerNorm)
+                if hasattr(L, 'lang_self_att'):      # text-side sub-layers, used by forward_mlm only
+                    packed(k + '.ckv', [L.visual_attention.att.key, L.visual_attention.att.value])
+                    packed(k + '.lqkv', [L.lang_self_att.self.query, L.lang_self_att.self.key, L.lang_self_att.self.value])
+                    lin(k + '.lso', L.lang_self_att.output.dense); ln(k + '.lsln', L.lang_self_att.output.LayerNorm)
+                    lin(k + '.lff1', L.lang_inter.dense); lin(k + '.lff2', L.lang_output.dense); ln(k + '.lfln', L.lang_output.LayerNorm)
         packed('x.txtkv', kv)       # [2 branches * layers * (K,V) * 768, 768]
+        self._head_weights(W, lin, ln, f)
+        if not grad:
+            self._wcache = W
+        return W
+
+    def _cls_head_weights(self, W, key, hd, lin, ln, f):
+        lin(key + '.l1', hd.net[0]); ln(key + '.ln', hd.net[2])
+        if hd.net[3].out_features == 1:
+            W[key + '.w2'], W[key + '.b2'] = f(hd.net[3].weight.reshape(-1)), f(hd.net[3].bias)
+        else:
+            lin(key + '.l2', hd.net[3])
+
+    def _head_weights(self, W, lin, ln, f):
         heads = [('head.g', self.global_sap_head), ('head.l', self.local_sap_head)]
         if self.sap_fuse_linear is not None:
             heads.append(('head.f', self.sap_fuse_linear))
         if hasattr(self, 'og_head'):
             heads.append(('head.o', self.og_head))
         for k, hd in heads:
-            lin(k + '.l1', hd.net[0]); ln(k + '.ln', hd.net[2])
-            W[k + '.w2'], W[k + '.b2'] = f(hd.net[3].weight.reshape(-1)), f(hd.net[3].bias)
+            self._cls_head_weights(W, k, hd, lin, ln, f)
         for k, m in (('pool.g', self.gmap_pooler), ('pool.v', self.vp_pooler), ('pool.t', self.txt_pooler)):
             lin(k, m.dense)
         lin('his.map', self.local_his_map); ln('his.ln', self.local_his_ln)
-        if not grad:
-            self._wcache = W
-        return W
 
     # ---------------------------------------------------------------- building blocks
     def _drop(self, x, p):
@@ -343,7 +364,7 @@ class GlocalTextPathNavCMT(nn.Module):
             x = self._bert_layer(W, 'lang.%d' % i, x, nh, tm, MASK_NEG10000)
         if not getattr(cfg, 'update_lang_bert', True):
             x = x.detach()
-        if obj_txt is None and not self.REVERIE:
+        if self.PRETRAIN or (obj_txt is None and not self.REVERIE):
             return x
         # IGL (vilmodel.py:521-528; REVERIE uses object words only, vilmodel_reverie.py:523-529)
         obj = nn.functional.embedding(obj_txt, W['emb.obj'])
@@ -477,36 +498,39 @@ class GlocalTextPathNavCMT(nn.Module):
                     src[i, j] = slot.get(vp, -2)
         return src, bw
 
-    def _x_layers(self, W, kv, txt_masks, feats, masks, dists):
-        """Global and local CrossmodalEncoders in lock-step: every GEMM is one grouped launch over both
-        branches (vilmodel.py:540-549, 454-469)."""
+    def _x_layers(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
+        """The CrossmodalEncoders of the branches in `brs` (global 'g', local 'l') in lock-step: every GEMM is one
+        grouped launch over the branches (vilmodel.py:540-549, 454-469)."""
         cfg = self.config
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
-        brs = ('g', 'l')
+        n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
         for i in range(nl):
             ks = ['x.%s.%d' % (b, i) for b in brs]
-            q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(2)])
+            q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(n)])
             a = []
-            for j in range(2):
-                off = ((j * nl + i) * 2) * H
+            for j in range(n):
+                off = ((('g', 'l').index(brs[j]) * nl + i) * 2) * H
                 a.append(Fn.attention(q[j], kv[..., off:off + H], kv[..., off + H:off + 2 * H], nh, txt_masks, MASK_NEG10000))
             feats = self._grouped_res_ln(W, ks, '.co', '.cln', a, feats, eps)
-            qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(2)])
-            a = [Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, masks[j], MASK_NEG10000,
-                              dists if j == 0 else None, sw if j == 0 else None, sb if j == 0 else None) for j in range(2)]
+            qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(n)])
+            a = []
+            for j in range(n):
+                sp = brs[j] == 'g' and dists is not None
+                a.append(Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, masks[j], MASK_NEG10000,
+                                      dists if sp else None, sw if sp else None, sb if sp else None))
             feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
-            inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(2)], act=ACT_GELU)
+            inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(n)], act=ACT_GELU)
             feats = self._grouped_res_ln(W, ks, '.ff2', '.fln', inter, feats, eps)
         return feats
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
-        p = self.config.hidden_dropout_prob
+        p, n = self.config.hidden_dropout_prob, len(ks)
         if self.training and p > 0:
-            z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], None) for j in range(2)], out_f32=True)
-            return [Fn.layernorm(self._drop(z[j], p), W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, residual=res[j]) for j in range(2)]
-        z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], res[j]) for j in range(2)], out_f32=True)
-        return [Fn.layernorm(z[j], W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, out_dtype=res[j].dtype) for j in range(2)]
+            z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], None) for j in range(n)], out_f32=True)
+            return [Fn.layernorm(self._drop(z[j], p), W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, residual=res[j]) for j in range(n)]
+        z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], res[j]) for j in range(n)], out_f32=True)
+        return [Fn.layernorm(z[j], W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, out_dtype=res[j].dtype) for j in range(n)]
 
     def _heads(self, W, items):
         """items: list of (key, x [..,K]) -> raw scores; first layers grouped in one launch (vilmodel.py:616-628)."""

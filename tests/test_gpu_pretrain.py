@@ -1,0 +1,61 @@
+"""gpu: HIP-backed GlocalTextPathCMTPreTraining vs the reference's own loss vectors, logits and gradient slices
+(tests/golden/r2r_pt.npz).  fp32 mode: losses/logits within 1e-3 (measured ~1e-5), gradient slices within 2e-3
+relative to the slice's max; bf16 mode: losses within 5e-2 relative, gradient norm within 5 %, gradient slices within 25 % of the slice max (bf16 recompute-backward)."""
+import numpy as np
+import pytest
+import torch
+
+from dsrg_amd import synth
+from tests import common
+from tests.test_oracle_pt_golden import PT_CFG
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dtype):
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain import GlocalTextPathCMTPreTraining
+    m = GlocalTextPathCMTPreTraining(DSRGConfig(**PT_CFG), compute_dtype=dtype)
+    ref = common.load_shapes('r2r_pt')
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref, (set(ref) ^ set(mine))
+    m.load_state_dict(common.synth_sd('r2r_pt'))
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pretrain_losses_and_grads(dtype):
+    gold = common.load_gold('r2r_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    m = _model(dtype)
+    fp32 = dtype == torch.float32
+    named = dict(m.named_parameters())
+    for task in ('mlm', 'mrc', 'sap'):
+        b = common.to_t(synth.pretrain_batch(B, L, O, seed, task), 'cuda')
+        m.zero_grad()
+        loss = m(b, task, compute_loss=True)
+        g = gold[task + '_loss']
+        err = np.abs(loss.detach().float().cpu().numpy() - g).max()
+        assert err <= (1e-3 if fp32 else 5e-2 * np.abs(g).max()), (task, err)
+        loss.mean().backward()
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+        assert abs(gn - gold[task + '_gradnorm'][0]) <= (2e-3 if fp32 else 5e-2) * gold[task + '_gradnorm'][0], (task, gn)
+        for k, gg in gold.items():
+            if k.startswith(task + '_grad:'):
+                mine = named[k.split(':', 1)[1]].grad.reshape(-1)[:64].float().cpu().numpy()
+                tol = (2e-3 if fp32 else 2.5e-1) * np.abs(gg).max() + 1e-6
+                assert np.abs(mine - gg).max() <= tol, (k, np.abs(mine - gg).max(), np.abs(gg).max())
+        with torch.no_grad():
+            o = m(b, task, compute_loss=False)
+        tol = 1e-3 if fp32 else 8e-2
+        if task == 'mlm':
+            assert np.abs(o[:, ::97].float().cpu().numpy() - gold['mlm_scores_s']).max() <= tol
+        elif task == 'mrc':
+            assert np.abs(o[0][:, ::13].float().cpu().numpy() - gold['mrc_logits_s']).max() <= tol
+        else:
+            for n, t in zip(('global_logits', 'local_logits', 'fused_logits'), o[:3]):
+                gg, t = gold['sap_' + n], t.float().cpu().numpy()
+                fin = np.isfinite(gg)
+                assert (np.isfinite(t) == fin).all() and np.abs(t[fin] - gg[fin]).max() <= tol
+    with pytest.raises(ValueError):
+        m(b, 'bogus')
