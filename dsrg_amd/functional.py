@@ -1,9 +1,12 @@
 """Differentiable ops of the DSRG hot path.
 
-Forward ALWAYS runs the hand-written HIP kernel (kernels.py -> libdsrg_hip.so); there is no other
-forward.  When autograd needs a gradient, the op is wrapped in `_Fused`: its backward re-expresses the
-op with ATen ops on the saved inputs and differentiates that (rocBLAS GEMMs + ATen elementwise).
-Round-1 status: backward is correct but not yet hand-written; see DESIGN.md "Backward".
+Forward ALWAYS runs the hand-written HIP kernel (kernels.py -> libdsrg_hip.so); there is no other forward.
+Backward:
+  * linear / grouped linear, dense(+dropout)+residual+LayerNorm, LayerNorm, activations: hand-written HIP
+    (dgrad / wgrad on the MFMA GEMM with transposed operands, LayerNorm-backward and activation-backward kernels,
+    bias column sums) -- >= 97 % of the backward FLOPs;
+  * attention, token-embedding sums, GAA pooling, head tails, logit fusion, IGL gate: `_Fused` -- the backward
+    re-expresses the op with ATen ops on the saved inputs and differentiates that (small ops; next to be replaced).
 """
 import math
 import torch
@@ -60,43 +63,202 @@ def _call(hip_fn, aten_fn, *args):
     return hip_fn(*args)
 
 
-# ----------------------------------------------------------------------------- linear (grouped)
-def _act(z, act):
-    if act == ACT_GELU:
-        return F.gelu(z)
-    if act == ACT_RELU:
-        return torch.relu(z)
-    if act == ACT_TANH:
-        return torch.tanh(z)
-    return z
+# ----------------------------------------------------------------------------- linear (grouped), hand-written backward
+def _as2d(t):
+    """[..., H] view with uniformly strided rows -> 2-D [M, H] view (no copy)."""
+    if t.dim() == 2:
+        return t
+    M, ld = K._rows(t)
+    return t.as_strided((M, t.shape[-1]), (ld, 1), t.storage_offset())
+
+
+def _gemm_grads(items):
+    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw) -> (dx list, dw list); every group of
+    dgrad / wgrad GEMMs is ONE grouped launch of the forward NT kernel on transposed operands."""
+    dxp, dwp = [], []
+    for x, w, dy, ndx, ndw in items:
+        N, Kd = w.shape
+        if ndx:
+            Np = (N + 63) // 64 * 64
+            dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
+            dxp.append((dyp, K.transpose_pad(w), None, None))            # [M,Np] x [K,Np]^T
+        if ndw:
+            dwp.append((K.transpose_pad(dy), K.transpose_pad(x), None, None))   # [N,Mp] x [K,Mp]^T
+    dxs = K.gemm(dxp) if dxp else []
+    dws = K.gemm(dwp) if dwp else []
+    outx, outw = [], []
+    for x, w, dy, ndx, ndw in items:
+        outx.append(dxs.pop(0) if ndx else None)
+        outw.append(dws.pop(0) if ndw else None)
+    return outx, outw
+
+
+class _LinearFn(torch.autograd.Function):
+    """y_i = x_i W_i^T + b_i (+ r_i), grouped.  Backward: dX = dY.W and dW = dY^T.X on the MFMA GEMM (transposed
+    operands, kernels.transpose_pad), db = column sums, dr = dY."""
+
+    @staticmethod
+    def forward(ctx, n, out_f32, *flat):
+        probs = [tuple(flat[4 * i:4 * i + 4]) for i in range(n)]
+        ctx.n = n
+        ctx.shapes = [p[0].shape for p in probs]
+        ctx.rdt = [None if p[3] is None else p[3].dtype for p in probs]
+        ctx.hasb = [p[2] is not None for p in probs]
+        ctx.save_for_backward(*[t for p in probs for t in (p[0], p[1])])
+        with torch.no_grad():
+            return tuple(K.gemm(probs, ACT_NONE, out_f32))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        sv = ctx.saved_tensors
+        items, res = [], [None, None]
+        for i in range(ctx.n):
+            x, w = sv[2 * i], sv[2 * i + 1]
+            dy = dys[i]
+            if dy is None:
+                items.append(None)
+                continue
+            dy2 = _as2d(dy if dy.stride(-1) == 1 else dy.contiguous())
+            if dy2.dtype != w.dtype:
+                dy2 = dy2.to(w.dtype)
+            items.append((_as2d(x), w, dy2, ctx.needs_input_grad[2 + 4 * i], ctx.needs_input_grad[3 + 4 * i]))
+        live = [it for it in items if it is not None]
+        dxs, dws = _gemm_grads(live) if live else ([], [])
+        for i in range(ctx.n):
+            if items[i] is None:
+                res += [None, None, None, None]
+                continue
+            dx, dw = dxs.pop(0), dws.pop(0)
+            dy2 = items[i][2]
+            db = K.colsum(dy2) if (ctx.hasb[i] and ctx.needs_input_grad[4 + 4 * i]) else None
+            dr = None
+            if ctx.rdt[i] is not None and ctx.needs_input_grad[5 + 4 * i]:
+                dr = dys[i].to(ctx.rdt[i])
+            res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw, db, dr]
+        return tuple(res)
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, act):
+        ctx.act = act
+        ctx.save_for_backward(z)
+        return K.act_fwd(z, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return K.act_bwd(z, dy.to(z.dtype), ctx.act), None
+
+
+def activation(z, act):
+    if act == ACT_NONE:
+        return z
+    if torch.is_grad_enabled() and z.requires_grad:
+        return _ActFn.apply(z, act)
+    return K.act_fwd(z, act)
+
+
+def _needs_grad(ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
 
 def linear_grouped(problems, act=ACT_NONE, out_f32=False):
-    """problems: list of (x, w, bias|None, residual|None) -> list of outputs; one kernel launch."""
-    n = len(problems)
+    """problems: list of (x, w, bias|None, residual|None) -> list of outputs; one kernel launch.
+    Inference: the activation is fused in the GEMM epilogue.  Under autograd the pre-activation is kept (the GEMM
+    runs with no activation and a separate element-wise kernel applies it) so the backward needs no recompute."""
     flat = [t for p in problems for t in p]
-
-    def hip(*a):
-        return K.gemm([tuple(a[4 * i:4 * i + 4]) for i in range(n)], act, out_f32)
-
-    def aten(*a):
-        outs = []
-        for i in range(n):
-            x, w, b, r = a[4 * i:4 * i + 4]
-            z = F.linear(x, w).float()
-            if b is not None:
-                z = z + b
-            z = _act(z, act)
-            if r is not None:
-                z = z + r.float()
-            outs.append(z if out_f32 else z.to(x.dtype))
-        return outs
-
-    return list(_call(hip, aten, *flat))
+    if not _needs_grad(flat):
+        return K.gemm(problems, act, out_f32)
+    if act != ACT_NONE and any(p[3] is not None for p in problems):
+        raise _lib.DsrgHipError('linear_grouped: activation together with a residual is not used on this path')
+    zs = _LinearFn.apply(len(problems), out_f32 and act == ACT_NONE, *flat)
+    if act == ACT_NONE:
+        return list(zs)
+    ys = [activation(z, act) for z in zs]
+    return [y.float() for y in ys] if out_f32 else ys
 
 
 def linear(x, w, b=None, act=ACT_NONE, residual=None, out_f32=False):
     return linear_grouped([(x, w, b, residual)], act, out_f32)[0]
+
+
+# ----------------------------------------------------------------------------- dense (+dropout) + residual + LayerNorm
+class _LinearLNFn(torch.autograd.Function):
+    """y_i = LN(drop(x_i W_i^T + b_i) + r_i) * gamma_i + beta_i, grouped (BertSelfOutput / BertOutput and every
+    Linear->LayerNorm pair).  The fp32 pre-LN sum is kept for the backward; backward = LN-backward kernel, then the
+    dgrad / wgrad GEMMs and the bias column sums."""
+
+    @staticmethod
+    def forward(ctx, n, eps, p_drop, *flat):
+        probs = [tuple(flat[6 * i:6 * i + 6]) for i in range(n)]      # x, w, b, r, gamma, beta
+        ctx.n, ctx.eps = n, eps
+        ctx.shapes = [p[0].shape for p in probs]
+        with torch.no_grad():
+            if p_drop > 0:
+                zs = K.gemm([(p[0], p[1], p[2], None) for p in probs], ACT_NONE, True)
+                masks = []
+                for z in zs:
+                    m = (torch.rand_like(z) >= p_drop).to(z.dtype).mul_(1.0 / (1.0 - p_drop))
+                    z.mul_(m)
+                    masks.append(m.to(probs[0][1].dtype))
+                ys = [K.layernorm(z, p[4], p[5], eps, p[3], p[1].dtype) for z, p in zip(zs, probs)]
+            else:
+                masks = [None] * n
+                zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in probs], ACT_NONE, True)
+                ys = [K.layernorm(z, p[4], p[5], eps, None, p[1].dtype) for z, p in zip(zs, probs)]
+        ctx.drop = p_drop > 0
+        ctx.hasr = [p[3] is not None for p in probs]
+        ctx.hasb = [p[2] is not None for p in probs]
+        saved = []
+        for p, z, m in zip(probs, zs, masks):
+            saved += [p[0], p[1], p[4], z] + ([p[3]] if (ctx.drop and p[3] is not None) else []) + ([m] if m is not None else [])
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        sv = list(ctx.saved_tensors)
+        items, keep = [], []
+        for i in range(ctx.n):
+            x, w, gamma, z = sv.pop(0), sv.pop(0), sv.pop(0), sv.pop(0)
+            r = sv.pop(0) if (ctx.drop and ctx.hasr[i]) else None
+            m = sv.pop(0) if ctx.drop else None
+            dy = dys[i]
+            if dy is None:
+                items.append(None); keep.append(None)
+                continue
+            dy = dy if dy.dtype == w.dtype else dy.to(w.dtype)
+            dz, dg, dbt = K.layernorm_bwd(z, r, gamma, dy, ctx.eps)
+            dlin = dz if m is None else dz * m
+            keep.append((dz, dg, dbt, dlin))
+            items.append((_as2d(x), w, _as2d(dlin), ctx.needs_input_grad[3 + 6 * i], ctx.needs_input_grad[4 + 6 * i]))
+        live = [it for it in items if it is not None]
+        dxs, dws = _gemm_grads(live) if live else ([], [])
+        res = [None, None, None]
+        for i in range(ctx.n):
+            if items[i] is None:
+                res += [None] * 6
+                continue
+            dz, dg, dbt, dlin = keep[i]
+            dx, dw = dxs.pop(0), dws.pop(0)
+            db = K.colsum(_as2d(dlin)) if (ctx.hasb[i] and ctx.needs_input_grad[5 + 6 * i]) else None
+            dr = dz if (ctx.hasr[i] and ctx.needs_input_grad[6 + 6 * i]) else None
+            res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw, db, dr, dg, dbt]
+        return tuple(res)
+
+
+def linear_ln_grouped(problems, eps, p_drop=0.0):
+    """problems: list of (x, w, b, residual|None, gamma, beta) -> list of LN(drop(xW^T+b) + residual)."""
+    flat = [t for p in problems for t in p]
+    if not _needs_grad(flat) and p_drop == 0.0:
+        zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in problems], ACT_NONE, True)
+        return [K.layernorm(z, p[4], p[5], eps, None, p[1].dtype) for z, p in zip(zs, problems)]
+    return list(_LinearLNFn.apply(len(problems), eps, float(p_drop), *flat))
+
+
+def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0):
+    return linear_ln_grouped([(x, w, b, residual, gamma, beta)], eps, p_drop)[0]
 
 
 # ----------------------------------------------------------------------------- attention
@@ -125,17 +287,27 @@ def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=
 
 
 # ----------------------------------------------------------------------------- layernorm
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, eps, odt):
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma, residual)
+        return K.layernorm(x, gamma, beta, eps, residual, odt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, residual = ctx.saved_tensors
+        dz, dg, db = K.layernorm_bwd(x, residual, gamma, dy, ctx.eps)
+        dx = dz if dz.dtype == x.dtype else dz.to(x.dtype)
+        dr = None if residual is None else (dz if dz.dtype == residual.dtype else dz.to(residual.dtype))
+        return dx, dg, db, dr, None, None
+
+
 def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
     odt = out_dtype or (residual.dtype if residual is not None else x.dtype)
-
-    def hip(x, g, b, r):
-        return K.layernorm(x, g, b, eps, r, odt, out)
-
-    def aten(x, g, b, r):
-        z = x.float() if r is None else x.float() + r.float()
-        return F.layer_norm(z, (z.shape[-1],), g, b, eps).to(odt)
-
-    return _call(hip, aten, x, gamma, beta, residual)
+    if out is None and _needs_grad((x, gamma, beta, residual)):
+        return _LayerNormFn.apply(x, gamma, beta, residual, eps, odt)
+    return K.layernorm(x, gamma, beta, eps, residual, odt, out)
 
 
 # ----------------------------------------------------------------------------- token embedding

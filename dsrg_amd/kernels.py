@@ -229,3 +229,57 @@ def igl_blend(aug, x, wa, ba, wo, bo):
     _lib.check(lib.dsrg_igl_blend_fwd(_p(aug), _p(x), _p(wa), _p(ba), _p(wo), _p(bo), _p(out), M, H, _dt(x),
                                       _stream()), 'dsrg_igl_blend_fwd')
     return out
+
+
+# ----------------------------------------------------------------------------- backward-pass kernels
+def transpose_pad(x, out_dtype=None, pad_to=64):
+    """x [R,C] (row stride free) -> [C, Rp] with Rp = R rounded up to pad_to, zero filled."""
+    lib = _lib.load()
+    _dev(x)
+    R, C_ = x.shape
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(C_, Rp, device=x.device, dtype=out_dtype or x.dtype)
+    _lib.check(lib.dsrg_transpose_pad(_p(x), x.stride(0), _p(out), Rp, R, C_, Rp, _dt(x), _dt(out), _stream()), 'dsrg_transpose_pad')
+    return out
+
+
+def colsum(x):
+    """x [M,N] -> fp32 [N]"""
+    lib = _lib.load()
+    _dev(x)
+    M, N = x.shape
+    out = torch.zeros(N, device=x.device, dtype=torch.float32)
+    _lib.check(lib.dsrg_colsum_acc(_p(x), x.stride(0), _p(out), M, N, _dt(x), _stream()), 'dsrg_colsum_acc')
+    return out
+
+
+def act_fwd(z, act):
+    lib = _lib.load()
+    _dev(z)
+    z = z.contiguous()
+    y = torch.empty_like(z)
+    _lib.check(lib.dsrg_act_fwd(_p(z), _p(y), z.numel(), act, _dt(z), _stream()), 'dsrg_act_fwd')
+    return y
+
+
+def act_bwd(z, dy, act):
+    lib = _lib.load()
+    z, dy = z.contiguous(), dy.contiguous()
+    dz = torch.empty_like(z)
+    _lib.check(lib.dsrg_act_bwd(_p(z), _p(dy), _p(dz), z.numel(), act, _dt(z), _stream()), 'dsrg_act_bwd')
+    return dz
+
+
+def layernorm_bwd(x, residual, gamma, dy, eps):
+    """returns dz (dtype of dy), dgamma, dbeta (fp32)"""
+    lib = _lib.load()
+    _dev(x)
+    M, ldx = _rows(x)
+    H = x.shape[-1]
+    dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+    dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
+    dg, db = torch.zeros(H, device=x.device, dtype=torch.float32), torch.zeros(H, device=x.device, dtype=torch.float32)
+    ldr = _rows(residual)[1] if residual is not None else 0
+    _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
+                                      _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')
+    return dz, dg, db

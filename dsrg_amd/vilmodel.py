@@ -333,13 +333,9 @@ class GlocalTextPathNavCMT(nn.Module):
         return nn.functional.dropout(x, p, True) if (self.training and p > 0) else x
 
     def _dense_res_ln(self, W, k_lin, k_ln, h, res, eps):
-        """LayerNorm(dense(h) + res): BertSelfOutput / BertOutput (vilmodel.py:173-177, 213-217)."""
-        p = self.config.hidden_dropout_prob
-        if self.training and p > 0:
-            z = Fn.linear(h, W[k_lin + '.w'], W[k_lin + '.b'], out_f32=True)
-            return Fn.layernorm(self._drop(z, p), W[k_ln + '.g'], W[k_ln + '.b'], eps, residual=res)
-        z = Fn.linear(h, W[k_lin + '.w'], W[k_lin + '.b'], residual=res, out_f32=True)
-        return Fn.layernorm(z, W[k_ln + '.g'], W[k_ln + '.b'], eps, out_dtype=res.dtype)
+        """LayerNorm(dropout(dense(h)) + res): BertSelfOutput / BertOutput (vilmodel.py:173-177, 213-217)."""
+        p = self.config.hidden_dropout_prob if self.training else 0.0
+        return Fn.linear_ln(h, W[k_lin + '.w'], W[k_lin + '.b'], W[k_ln + '.g'], W[k_ln + '.b'], eps, residual=res, p_drop=p)
 
     def _bert_layer(self, W, key, x, nh, kmask, mode):  # vilmodel.py:226-232
         H, eps = x.shape[-1], self.config.layer_norm_eps
@@ -438,8 +434,7 @@ class GlocalTextPathNavCMT(nn.Module):
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, V, _ = view_img_fts.shape
         H, d = cfg.hidden_size, cfg.obj_v2_size
-        img = Fn.layernorm(Fn.linear(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], out_f32=True),
-                           W['img.ln.g'], W['img.ln.b'], 1e-12, out_dtype=cd)
+        img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
         obj_rows, O = self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types)
         x = self._pano_tokens(W, img, loc_fts, nav_types)
         pano_masks = torch.arange(V, device=x.device)[None] < view_lens[:, None]
@@ -448,8 +443,7 @@ class GlocalTextPathNavCMT(nn.Module):
         cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
                             lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
                             B, V, H, d, x.device)
-        pano = Fn.layernorm(Fn.linear(cat, W['visobj.lin.w'], W['visobj.lin.b'], out_f32=True),
-                            W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out_dtype=cd)
+        pano = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12)
         fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'])
         return pano, pano_masks, fused
 
@@ -525,12 +519,9 @@ class GlocalTextPathNavCMT(nn.Module):
         return feats
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
-        p, n = self.config.hidden_dropout_prob, len(ks)
-        if self.training and p > 0:
-            z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], None) for j in range(n)], out_f32=True)
-            return [Fn.layernorm(self._drop(z[j], p), W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, residual=res[j]) for j in range(n)]
-        z = Fn.linear_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], res[j]) for j in range(n)], out_f32=True)
-        return [Fn.layernorm(z[j], W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'], eps, out_dtype=res[j].dtype) for j in range(n)]
+        p = self.config.hidden_dropout_prob if self.training else 0.0
+        return Fn.linear_ln_grouped([(hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], res[j], W[ks[j] + ln + '.g'], W[ks[j] + ln + '.b'])
+                                     for j in range(len(ks))], eps, p)
 
     def _heads(self, W, items):
         """items: list of (key, x [..,K]) -> raw scores; first layers grouped in one launch (vilmodel.py:616-628)."""
@@ -587,8 +578,7 @@ class GlocalTextPathNavCMT(nn.Module):
             pooled = torch.empty(B, 3 * H, device=dev, dtype=cd)
             K.gemm([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], ACT_TANH,
                    outs=[pooled[:, j * H:(j + 1) * H] for j in range(3)])
-        cls = Fn.layernorm(Fn.linear(pooled, W['his.map.w'], W['his.map.b'], out_f32=True), W['his.ln.g'], W['his.ln.b'],
-                           cfg.layer_norm_eps, out_dtype=cd)
+        cls = Fn.linear_ln(pooled, W['his.map.w'], W['his.map.b'], W['his.ln.g'], W['his.ln.b'], cfg.layer_norm_eps)
         return {'gmap_embeds': g, 'vp_embeds': v, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fl,
                 'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls}
 

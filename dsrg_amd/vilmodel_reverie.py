@@ -30,12 +30,10 @@ class GlocalTextPathNavCMT(_Base):
                             else Fn.layernorm(z, g, b, 1e-12, out_dtype=cd),
                             lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
                             B, V, H, d, dev)
-        view = Fn.layernorm(Fn.linear(cat, W['visobj.lin.w'], W['visobj.lin.b'], out_f32=True),
-                            W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out_dtype=cd)
+        view = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12)
         if obj_img_fts is not None:
             No = obj_img_fts.shape[1]
-            o1 = Fn.layernorm(Fn.linear(obj_img_fts.to(cd), W['objv1.lin.w'], W['objv1.lin.b'], out_f32=True),
-                              W['objv1.ln.g'], W['objv1.ln.b'], 1e-12, out_dtype=cd)
+            o1 = Fn.linear_ln(obj_img_fts.to(cd), W['objv1.lin.w'], W['objv1.lin.b'], W['objv1.ln.g'], W['objv1.ln.b'], 1e-12)
             # per-episode [views[:vl] ; objects[:ol] ; zero pad] as one gather (reference: Python loop :727-735)
             T = nav_types.shape[1]
             lens = view_lens + obj_lens

@@ -134,6 +134,31 @@ int dsrg_nav_logits_fwd(const float* g_raw, const float* l_raw, const float* fus
 int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo,
                        const float* bo, void* out, int M, int H, int dtype, void* stream);
 
+/* ======================= backward pass =======================================================================
+ * The reference has no explicit backward code: these replace what torch.autograd derives for the ops above
+ * (loss.backward() at finetune_src/r2r/agent_base.py:205, pretrain_src/train_r2r.py:251-261).
+ * GEMM gradients reuse dsrg_gemm_nt:  dX = gemm_nt(dY, Wt),  dW = gemm_nt(dYt, Xt)  with the transposes below. */
+
+/* out[c, r] = in[r, c] for r < R (zero for R <= r < Rp), c < C.  in is [R,C] (ld_in) of in_dtype, out is [C,Rp] (ld_out)
+ * of out_dtype.  Rp is the row count padded to the GEMM's K granularity (64). */
+int dsrg_transpose_pad(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rp, int in_dtype,
+                       int out_dtype, void* stream);
+
+/* out[n] += sum_m in[m, n]  (bias gradient; out is fp32 and must be zeroed by the caller; float atomics). */
+int dsrg_colsum_acc(const void* in, int ld, float* out, int M, int N, int dtype, void* stream);
+
+/* y = act(z) and dz = dy * act'(z) element-wise (act = DSRG_ACT_*; erf-GELU of FT/vilmodel.py:30-31, ReLU of
+ * ClsPrediction :623, tanh of BertPooler :279).  n elements, n % 4 == 0. */
+int dsrg_act_fwd(const void* z, void* y, int64_t n, int act, int dtype, void* stream);
+int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, int act, int dtype, void* stream);
+
+/* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
+ *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].
+ * x is `in_dtype` (fp32 pre-LN sums or `dtype`), residual / dy / dz are `dtype`. */
+int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy,
+                       int lddy, void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps,
+                       int in_dtype, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,3 +183,79 @@ def test_errors_are_loud(K):
         K.gemm([(x, w, None, None)])            # K not a multiple of 32
     with pytest.raises(DsrgHipError):
         K.gemm([(x.cpu(), w.cpu(), None, None)])  # no CPU path
+
+
+# ----------------------------------------------------------------------------- backward kernels
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_transpose_colsum_act(K, dtype):
+    x = _r(1000, 130, dtype=dtype)
+    t = K.transpose_pad(x)
+    assert t.shape == (130, 1024)
+    assert torch.equal(t[:, :1000], x.t()) and (t[:, 1000:] == 0).all()
+    t2 = K.transpose_pad(_r(77, 768), out_dtype=dtype)
+    assert t2.dtype == dtype and t2.shape == (768, 128)
+    s = K.colsum(x)
+    assert (s - x.float().sum(0)).abs().max().item() <= (1e-3 if dtype == torch.float32 else 2e-1)
+    z = _r(64, 3072, dtype=dtype)
+    dy = _r(64, 3072, seed=1, dtype=dtype)
+    for act in (1, 2, 3):
+        zz = z.float().clone().requires_grad_(True)
+        yy = ACTS[act](zz)
+        yy.backward(dy.float())
+        tol = 1e-5 if dtype == torch.float32 else 3e-2
+        assert (K.act_fwd(z, act).float() - yy).abs().max().item() <= tol
+        assert (K.act_bwd(z, dy, act).float() - zz.grad).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('H,xf32,res', [(768, True, True), (768, False, False), (128, True, True)])
+def test_layernorm_bwd(K, dtype, H, xf32, res):
+    M = 333
+    x = _r(M, H, dtype=torch.float32 if xf32 else dtype)
+    r = _r(M, H, seed=1, dtype=dtype) if res else None
+    g, b = 1 + 0.1 * _r(H, seed=2), 0.1 * _r(H, seed=3)
+    dy = _r(M, H, seed=4, dtype=dtype)
+    dz, dg, db = K.layernorm_bwd(x, r, g, dy, 1e-12)
+    zz = (x.float() + (r.float() if res else 0)).requires_grad_(True)
+    gg = g.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(zz, (H,), gg, bb, 1e-12).backward(dy.float())
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    assert (dz.float() - zz.grad).abs().max().item() <= tol
+    assert (dg - gg.grad).abs().max().item() <= tol * 30 and (db - bb.grad).abs().max().item() <= tol * 30
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_functional_grads_match_autograd(dtype):
+    """grouped linear (+GELU), dense+residual+LN composite and LayerNorm: HIP backward vs torch autograd."""
+    from dsrg_amd import functional as Fn
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+
+    def leaf(*shape, seed=0, scale=1.0, dt=dtype):
+        return _r(*shape, seed=seed, scale=scale, dtype=dt).requires_grad_(True)
+    xs = [leaf(4, 20, 768), leaf(4, 38, 768, seed=1)]
+    ws = [leaf(3072, 768, seed=2, scale=0.03), leaf(3072, 768, seed=3, scale=0.03)]
+    bs = [leaf(3072, seed=4, dt=torch.float32), leaf(3072, seed=5, dt=torch.float32)]
+    w2 = [leaf(768, 3072, seed=6, scale=0.02), leaf(768, 3072, seed=7, scale=0.02)]
+    b2 = [leaf(768, seed=8, dt=torch.float32), leaf(768, seed=9, dt=torch.float32)]
+    gm = [leaf(768, seed=10, scale=0.1, dt=torch.float32), leaf(768, seed=11, scale=0.1, dt=torch.float32)]
+    bt = [leaf(768, seed=12, scale=0.1, dt=torch.float32), leaf(768, seed=13, scale=0.1, dt=torch.float32)]
+    leaves = xs + ws + bs + w2 + b2 + gm + bt
+    hs = Fn.linear_grouped([(xs[j], ws[j], bs[j], None) for j in range(2)], act=1)
+    ys = Fn.linear_ln_grouped([(hs[j], w2[j], b2[j], xs[j], gm[j] + 1, bt[j]) for j in range(2)], 1e-12)
+    ys = [Fn.layernorm(y, gm[j] + 1, bt[j], 1e-5) for j, y in enumerate(ys)]
+    up = [_r(*y.shape, seed=20 + j) for j, y in enumerate(ys)]
+    sum((y.float() * u).sum() for y, u in zip(ys, up)).backward()
+    mine = [t.grad.float().clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    F = torch.nn.functional
+    ref_y = []
+    for j in range(2):
+        h = F.gelu(F.linear(xs[j].float(), ws[j].float(), bs[j]))
+        y = F.layer_norm(F.linear(h, w2[j].float(), b2[j]) + xs[j].float(), (768,), gm[j] + 1, bt[j], 1e-12)
+        ref_y.append(F.layer_norm(y, (768,), gm[j] + 1, bt[j], 1e-5))
+    sum((y * u).sum() for y, u in zip(ref_y, up)).backward()
+    for t, m in zip(leaves, mine):
+        ref = t.grad.float()
+        err = (m - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), (tuple(t.shape), err, ref.abs().max().item())
