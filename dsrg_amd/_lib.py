@@ -10,7 +10,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 MAX_GROUPS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GemmProblem(C.Structure):
@@ -26,7 +26,9 @@ SIGNATURES = {
     'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
     'dsrg_gemm_nt_plan': (C.c_int, [C.POINTER(GemmProblem), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dsrg_attention_fwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _P, _P,
-                                     _I, _I, _I, _I, _F, _I, _P]),
+                                     _I, _I, _I, _I, _F, _P, _I, _P]),
+    'dsrg_attention_bwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
                                     _P, _I, _I, _I, _I, _P]),

@@ -18,6 +18,8 @@ struct AttnArgs {
   const uint8_t* kmask; int mask_mode;
   const float* dists; const float* sprel_w; const float* sprel_b;
   int Nq, Nk; float scale;
+  float* lse;   // [B,NH,Nq] log-sum-exp of the scores (NULL unless a backward pass will follow)
+  int NH;
 };
 
 template <typename T>
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const int qg = q0 + wave * QW + i;
     if (qg >= a.Nq) continue;
     Elem<T>::st(Op + (size_t)qg * a.o_rs + lane, o[i] / l[i]);
+    if (a.lse && lane == 0) a.lse[((size_t)b * a.NH + h) * a.Nq + qg] = m[i] + logf(l[i]);
   }
 }
 
@@ -278,6 +281,232 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       st4(Op + (size_t)qrow * a.o_rs + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
+    if (a.lse && g == 0) a.lse[((size_t)b * a.NH + h) * a.Nq + qrow] = m_run + logf(l_run);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward (fp32 arithmetic, recompute from Q, K, V and the forward's log-sum-exp; no score matrix in HBM).
+//   p_ij = exp(s_ij - lse_i),  dp_ij = dO_i . v_j,  delta_i = dO_i . O_i,  ds_ij = p_ij (dp_ij - delta_i)
+//   dQ_i = scale * sum_j ds_ij k_j      dK_j = scale * sum_i ds_ij q_i      dV_j = sum_i p_ij dO_i
+//   d(sprel_w) = sum ds_ij * dist_ij    d(sprel_b) = sum ds_ij
+// Two kernels so that no gradient needs a cross-workgroup sum except the two sprel scalars (float atomics):
+//   attention_bwd_dq : grid (ceil(Nq/16), NH, B), wave per query row, lane <-> key, 64-key tiles (also writes delta);
+//   attention_bwd_dkv: grid (ceil(Nk/64), NH, B), lane <-> key of the tile, the 4 waves split the queries and each
+//                      lane keeps dK_j, dV_j (2 x 64 floats) in registers; waves are combined through LDS.
+struct AttnBwdArgs {
+  AttnArgs f;                 // forward operands (O = forward output)
+  const void* dO; int64_t do_bs; int do_rs;
+  void *dQ, *dK, *dV;         // contiguous [B,N,NH*64]
+  float* delta;               // [B,NH,Nq] workspace
+  float* dsprel;              // [2] (w, b) accumulated with atomics, or NULL
+};
+
+__device__ __forceinline__ float mask_term(const AttnArgs& a, int b, int key, bool& dead) {
+  float t = 0.f;
+  dead = key >= a.Nk;
+  if (!dead && a.kmask) {
+    const bool mk = a.kmask[(size_t)b * a.Nk + key] != 0;
+    if (a.mask_mode == DSRG_MASK_NEG10000) t = mk ? 0.f : -10000.0f;
+    else if (a.mask_mode == DSRG_MASK_NEGINF) dead = !mk;
+    else if (a.mask_mode == DSRG_MASK_PLUS1) t = mk ? 1.0f : 0.f;
+  }
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs ba) {
+  const AttnArgs& a = ba.f;
+  __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * KPAD];
+  __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
+  __shared__ __attribute__((aligned(16))) float Gs[QPB * DH];   // dO rows
+  __shared__ __attribute__((aligned(16))) float Ds[4 * KT];     // ds of the wave's current row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QPB;
+  const T* Qp = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * DH;
+  const T* Kp = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * DH;
+  const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
+  const T* Op = reinterpret_cast<const T*>(a.O) + b * a.o_bs + h * DH;
+  const T* Gp = reinterpret_cast<const T*>(ba.dO) + b * ba.do_bs + h * DH;
+  T* dQp = reinterpret_cast<T*>(ba.dQ) + ((size_t)b * a.Nq) * (a.NH * DH) + h * DH;
+  {
+    const int r = tid >> 4, c = (tid & 15) * 4;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+    if (q0 + r < a.Nq) { qv = ld4(Qp + (size_t)(q0 + r) * a.q_rs + c); gv = ld4(Gp + (size_t)(q0 + r) * ba.do_rs + c); }
+    *reinterpret_cast<float4*>(&Qs[r * DH + c]) = qv;
+    *reinterpret_cast<float4*>(&Gs[r * DH + c]) = gv;
+  }
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+  float dq[QW], lse[QW], delta[QW], gsw = 0.f, gsb = 0.f;
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int qg = q0 + wave * QW + i;
+    dq[i] = 0.f; lse[i] = 0.f; delta[i] = 0.f;
+    if (qg < a.Nq) {
+      const float g = Elem<T>::ld(Gp + (size_t)qg * ba.do_rs + lane), o = Elem<T>::ld(Op + (size_t)qg * a.o_rs + lane);
+      delta[i] = wave_sum(g * o);
+      lse[i] = a.lse[((size_t)b * a.NH + h) * a.Nq + qg];
+      if (lane == 0) ba.delta[((size_t)b * a.NH + h) * a.Nq + qg] = delta[i];
+    }
+  }
+  for (int k0 = 0; k0 < a.Nk; k0 += KT) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (k0 + r < a.Nk) { kv = ld4(Kp + (size_t)(k0 + r) * a.k_rs + c); vv = ld4(Vp + (size_t)(k0 + r) * a.v_rs + c); }
+      *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = kv;
+      *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = vv;
+    }
+    __syncthreads();
+    const int key = k0 + lane;
+    bool dead;
+    const float mterm = mask_term(a, b, key, dead);
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+      const int ql = wave * QW + i, qg = q0 + ql;
+      if (qg >= a.Nq) continue;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(&Ks[lane * KPAD + c]);
+        const float4 vv = *reinterpret_cast<const float4*>(&Vs[lane * KPAD + c]);
+        const float4 qq = *reinterpret_cast<const float4*>(&Qs[ql * DH + c]);
+        const float4 gg = *reinterpret_cast<const float4*>(&Gs[ql * DH + c]);
+        s = fmaf(qq.x, kk.x, s); s = fmaf(qq.y, kk.y, s); s = fmaf(qq.z, kk.z, s); s = fmaf(qq.w, kk.w, s);
+        dp = fmaf(gg.x, vv.x, dp); dp = fmaf(gg.y, vv.y, dp); dp = fmaf(gg.z, vv.z, dp); dp = fmaf(gg.w, vv.w, dp);
+      }
+      s = s * a.scale + mterm;
+      float dist = 0.f;
+      if (a.dists && !dead) { dist = a.dists[((size_t)b * a.Nq + qg) * a.Nk + key]; s += dist * sw + sb; }
+      const float p = dead ? 0.f : __expf(s - lse[i]);
+      const float ds = p * (dp - delta[i]);
+      gsw += ds * dist; gsb += ds;
+      Ds[wave * KT + lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+      float acc = dq[i];
+#pragma unroll 8
+      for (int j = 0; j < KT; j += 4) {
+        const float4 dd = *reinterpret_cast<const float4*>(&Ds[wave * KT + j]);
+        acc = fmaf(dd.x, Ks[(j + 0) * KPAD + lane], acc);
+        acc = fmaf(dd.y, Ks[(j + 1) * KPAD + lane], acc);
+        acc = fmaf(dd.z, Ks[(j + 2) * KPAD + lane], acc);
+        acc = fmaf(dd.w, Ks[(j + 3) * KPAD + lane], acc);
+      }
+      dq[i] = acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < QW; ++i) {
+    const int qg = q0 + wave * QW + i;
+    if (qg < a.Nq) Elem<T>::st(dQp + (size_t)qg * (a.NH * DH) + lane, dq[i] * a.scale);
+  }
+  if (ba.dsprel && a.dists) {
+    gsw = wave_sum(gsw); gsb = wave_sum(gsb);
+    if (lane == 0) { atomicAdd(ba.dsprel, gsw); atomicAdd(ba.dsprel + 1, gsb); }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArgs ba) {
+  const AttnArgs& a = ba.f;
+  __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * KPAD];
+  __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
+  __shared__ __attribute__((aligned(16))) float Gs[QPB * DH];
+  __shared__ float Ls[QPB], Dl[QPB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * KT;
+  const T* Qp = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * DH;
+  const T* Kp = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * DH;
+  const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
+  const T* Gp = reinterpret_cast<const T*>(ba.dO) + b * ba.do_bs + h * DH;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (k0 + r < a.Nk) { kv = ld4(Kp + (size_t)(k0 + r) * a.k_rs + c); vv = ld4(Vp + (size_t)(k0 + r) * a.v_rs + c); }
+    *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = kv;
+    *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = vv;
+  }
+  const int key = k0 + lane;
+  bool dead;
+  const float mterm = mask_term(a, b, key, dead);
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+  float dk[DH], dv[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int q0 = 0; q0 < a.Nq; q0 += QPB) {
+    __syncthreads();
+    {
+      const int r = tid >> 4, c = (tid & 15) * 4;
+      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+      if (q0 + r < a.Nq) { qv = ld4(Qp + (size_t)(q0 + r) * a.q_rs + c); gv = ld4(Gp + (size_t)(q0 + r) * ba.do_rs + c); }
+      *reinterpret_cast<float4*>(&Qs[r * DH + c]) = qv;
+      *reinterpret_cast<float4*>(&Gs[r * DH + c]) = gv;
+      if (tid < QPB) {
+        const bool ok = q0 + tid < a.Nq;
+        Ls[tid] = ok ? a.lse[((size_t)b * a.NH + h) * a.Nq + q0 + tid] : 0.f;
+        Dl[tid] = ok ? ba.delta[((size_t)b * a.NH + h) * a.Nq + q0 + tid] : 0.f;
+      }
+    }
+    __syncthreads();
+    for (int i = wave; i < QPB; i += 4) {          // the 4 waves split the query rows
+      const int qg = q0 + i;
+      if (qg >= a.Nq) break;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(&Ks[lane * KPAD + c]);
+        const float4 vv = *reinterpret_cast<const float4*>(&Vs[lane * KPAD + c]);
+        const float4 qq = *reinterpret_cast<const float4*>(&Qs[i * DH + c]);
+        const float4 gg = *reinterpret_cast<const float4*>(&Gs[i * DH + c]);
+        s = fmaf(qq.x, kk.x, s); s = fmaf(qq.y, kk.y, s); s = fmaf(qq.z, kk.z, s); s = fmaf(qq.w, kk.w, s);
+        dp = fmaf(gg.x, vv.x, dp); dp = fmaf(gg.y, vv.y, dp); dp = fmaf(gg.z, vv.z, dp); dp = fmaf(gg.w, vv.w, dp);
+      }
+      s = s * a.scale + mterm;
+      if (a.dists && !dead) s += a.dists[((size_t)b * a.Nq + qg) * a.Nk + key] * sw + sb;
+      const float p = dead ? 0.f : __expf(s - Ls[i]);
+      const float ds = p * (dp - Dl[i]) * a.scale;
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        const float4 qq = *reinterpret_cast<const float4*>(&Qs[i * DH + c]);
+        const float4 gg = *reinterpret_cast<const float4*>(&Gs[i * DH + c]);
+        dk[c] = fmaf(ds, qq.x, dk[c]); dk[c + 1] = fmaf(ds, qq.y, dk[c + 1]); dk[c + 2] = fmaf(ds, qq.z, dk[c + 2]); dk[c + 3] = fmaf(ds, qq.w, dk[c + 3]);
+        dv[c] = fmaf(p, gg.x, dv[c]); dv[c + 1] = fmaf(p, gg.y, dv[c + 1]); dv[c + 2] = fmaf(p, gg.z, dv[c + 2]); dv[c + 3] = fmaf(p, gg.w, dv[c + 3]);
+      }
+    }
+  }
+  // combine the 4 waves: reuse Ks / Vs as [64][68] accumulators
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < DH; c += 4) {
+        float4 ak = make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]), av = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+        if (w > 0) {
+          const float4 pk = *reinterpret_cast<const float4*>(&Ks[lane * KPAD + c]), pv = *reinterpret_cast<const float4*>(&Vs[lane * KPAD + c]);
+          ak.x += pk.x; ak.y += pk.y; ak.z += pk.z; ak.w += pk.w;
+          av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
+        }
+        *reinterpret_cast<float4*>(&Ks[lane * KPAD + c]) = ak;
+        *reinterpret_cast<float4*>(&Vs[lane * KPAD + c]) = av;
+      }
+    }
+    __syncthreads();
+  }
+  T* dKp = reinterpret_cast<T*>(ba.dK) + ((size_t)b * a.Nk) * (a.NH * DH) + h * DH;
+  T* dVp = reinterpret_cast<T*>(ba.dV) + ((size_t)b * a.Nk) * (a.NH * DH) + h * DH;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+    if (k0 + r < a.Nk) {
+      st4(dKp + (size_t)(k0 + r) * (a.NH * DH) + c, *reinterpret_cast<const float4*>(&Ks[r * KPAD + c]));
+      st4(dVp + (size_t)(k0 + r) * (a.NH * DH) + c, *reinterpret_cast<const float4*>(&Vs[r * KPAD + c]));
+    }
   }
 }
 
@@ -287,7 +516,7 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
                                   const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
                                   const uint8_t* kmask, int mask_mode, const float* pair_dists,
                                   const float* sprel_w, const float* sprel_b,
-                                  int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream) {
+                                  int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream) {
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_fwd: bad dtype %d", dtype);
   DSRG_CHECK(Q && K && V && O, "dsrg_attention_fwd: null Q/K/V/O");
   DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0 && Nk >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_fwd: bad dims B=%d NH=%d Nq=%d Nk=%d", B, NH, Nq, Nk);
@@ -302,7 +531,7 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
   DSRG_CHECK(((uintptr_t)Q & am) == 0 && ((uintptr_t)K & am) == 0 && ((uintptr_t)V & am) == 0, "dsrg_attention_fwd: misaligned Q/K/V");
   if (B == 0 || Nq == 0) return DSRG_OK;
   AttnArgs a{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask, mask_mode,
-             pair_dists, sprel_w, sprel_b, Nq, Nk, scale};
+             pair_dists, sprel_w, sprel_b, Nq, Nk, scale, lse, NH};
   dim3 grid((Nq + QPB - 1) / QPB, NH, B), block(256);
   const bool mfma_ok = dtype == DSRG_BF16 && q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
                        v_bs % 8 == 0 && o_rs % 4 == 0 && o_bs % 4 == 0 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 &&
@@ -315,5 +544,39 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
   if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
   DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                                  const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                                  const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                                  const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                                  const float* sprel_w, const float* sprel_b,
+                                  void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
+                                  int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream) {
+  DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_bwd: bad dtype %d", dtype);
+  DSRG_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws, "dsrg_attention_bwd: null pointer");
+  DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0 && Nk >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_bwd: bad dims");
+  DSRG_CHECK(mask_mode >= DSRG_MASK_NONE && mask_mode <= DSRG_MASK_PLUS1 && (mask_mode == DSRG_MASK_NONE || kmask), "dsrg_attention_bwd: bad mask");
+  DSRG_CHECK(!pair_dists || (sprel_w && sprel_b), "dsrg_attention_bwd: pair_dists needs sprel_w and sprel_b");
+  DSRG_CHECK(q_rs % 4 == 0 && k_rs % 4 == 0 && v_rs % 4 == 0 && o_rs % 4 == 0 && do_rs % 4 == 0 && q_bs % 4 == 0 && k_bs % 4 == 0 &&
+                 v_bs % 4 == 0 && o_bs % 4 == 0 && do_bs % 4 == 0, "dsrg_attention_bwd: strides must be multiples of 4 elements");
+  const uintptr_t am = dtype == DSRG_BF16 ? 7 : 15;
+  DSRG_CHECK((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO | (uintptr_t)dQ | (uintptr_t)dK | (uintptr_t)dV) & am) == 0,
+             "dsrg_attention_bwd: misaligned pointer");
+  if (B == 0 || Nq == 0) return DSRG_OK;
+  AttnBwdArgs ba{{Q, K, V, const_cast<void*>(O), q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask,
+                  mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH},
+                 dO, do_bs, do_rs, dQ, dK, dV, delta_ws, dsprel};
+  hipStream_t s = (hipStream_t)stream;
+  dim3 gq((Nq + QPB - 1) / QPB, NH, B), gk((Nk + KT - 1) / KT, NH, B), block(256);
+  if (dtype == DSRG_F32) {
+    hipLaunchKernelGGL((attention_bwd_dq_kernel<float>), gq, block, 0, s, ba);
+    hipLaunchKernelGGL((attention_bwd_dkv_kernel<float>), gk, block, 0, s, ba);
+  } else {
+    hipLaunchKernelGGL((attention_bwd_dq_kernel<bf16_t>), gq, block, 0, s, ba);
+    hipLaunchKernelGGL((attention_bwd_dkv_kernel<bf16_t>), gk, block, 0, s, ba);
+  }
+  DSRG_LAUNCH_CHECK("dsrg_attention_bwd");
   return DSRG_OK;
 }

@@ -5,7 +5,8 @@ Backward:
   * linear / grouped linear, dense(+dropout)+residual+LayerNorm, LayerNorm, activations: hand-written HIP
     (dgrad / wgrad on the MFMA GEMM with transposed operands, LayerNorm-backward and activation-backward kernels,
     bias column sums) -- >= 97 % of the backward FLOPs;
-  * attention, token-embedding sums, GAA pooling, head tails, logit fusion, IGL gate: `_Fused` -- the backward
+  * attention: two recompute kernels (dQ; dK/dV) from the forward's log-sum-exp, fp32 arithmetic;
+  * token-embedding sums, GAA pooling, head tails, logit fusion, IGL gate: `_Fused` -- the backward
     re-expresses the op with ATen ops on the saved inputs and differentiates that (small ops; next to be replaced).
 """
 import math
@@ -262,28 +263,29 @@ def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0):
 
 
 # ----------------------------------------------------------------------------- attention
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kmask, dists, sw, sb, nh, mask_mode, scale):
+        out, lse = K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sw, sb, scale, want_lse=True)
+        ctx.cfg = (nh, mask_mode, scale)
+        ctx.save_for_backward(q, k, v, out, lse, kmask, dists, sw, sb)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, out, lse, kmask, dists, sw, sb = ctx.saved_tensors
+        nh, mask_mode, scale = ctx.cfg
+        dq, dk, dv, dsp = K.attention_bwd(q, k, v, out, do.to(q.dtype), lse, nh, kmask, mask_mode, dists, sw, sb, scale)
+        dsw = dsb = None
+        if dsp is not None:
+            dsw, dsb = dsp[0:1].reshape(sw.shape).to(sw.dtype), dsp[1:2].reshape(sb.shape).to(sb.dtype)
+        return dq, dk, dv, None, None, dsw, dsb, None, None, None
+
+
 def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125):
-    def hip(q, k, v, kmask, dists, sw, sb):
-        return K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sw, sb, scale)
-
-    def aten(q, k, v, kmask, dists, sw, sb):
-        B, Nq, _ = q.shape
-        sp = lambda t: t.reshape(B, t.shape[1], nh, 64).permute(0, 2, 1, 3).float()
-        s = sp(q) @ sp(k).transpose(-1, -2) * scale
-        if kmask is not None:
-            m = kmask[:, None, None, :]
-            if mask_mode == MASK_NEG10000:
-                s = s + (1.0 - m.float()) * -10000.0
-            elif mask_mode == MASK_NEGINF:
-                s = s.masked_fill(~m, float('-inf'))
-            elif mask_mode == MASK_PLUS1:
-                s = s + m.float()
-        if dists is not None:
-            s = s + (dists * sw.reshape(()) + sb.reshape(()))[:, None]
-        o = torch.softmax(s, -1) @ sp(v)
-        return o.permute(0, 2, 1, 3).reshape(B, Nq, nh * 64).to(q.dtype)
-
-    return _call(hip, aten, q, k, v, kmask, dists, sprel_w, sprel_b)
+    if _needs_grad((q, k, v, sprel_w, sprel_b)):
+        return _AttentionFn.apply(q, k, v, kmask, dists, sprel_w, sprel_b, nh, mask_mode, scale)
+    return K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sprel_w, sprel_b, scale)
 
 
 # ----------------------------------------------------------------------------- layernorm

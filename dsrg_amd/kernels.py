@@ -104,7 +104,8 @@ def gemm_replay(rec):
     _lib.check(_lib.load().dsrg_gemm_nt(rec['arr'], rec['n'], rec['dt'], rec['odt'], rec['act'], _stream()), 'dsrg_gemm_nt')
 
 
-def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125):
+def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125,
+              want_lse=False):
     """q [B,Nq,nh*64], k/v [B,Nk,nh*64] views (row/batch strides free, last dim contiguous)."""
     lib = _lib.load()
     _dev(q)
@@ -120,12 +121,33 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     if dists is not None:
         if dists.dtype != torch.float32 or dists.shape != (B, Nq, Nk) or not dists.is_contiguous():
             raise _lib.DsrgHipError('attention: pair_dists must be contiguous fp32 [B,Nq,Nk]')
+    lse = torch.empty(B, nh, Nq, device=q.device, dtype=torch.float32) if want_lse else None
     bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
     _lib.check(lib.dsrg_attention_fwd(
         _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1),
         _p(out), out.stride(0), out.stride(1), _p(kmask), mask_mode, _p(dists), _p(sprel_w), _p(sprel_b),
-        B, nh, Nq, Nk, float(scale), _dt(q), _stream()), 'dsrg_attention_fwd')
-    return out
+        B, nh, Nq, Nk, float(scale), _p(lse), _dt(q), _stream()), 'dsrg_attention_fwd')
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125):
+    """-> dq, dk, dv (contiguous), dsprel fp32 [2] (or None)"""
+    lib = _lib.load()
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    do = do if do.stride(2) == 1 else do.contiguous()
+    dq = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
+    dk = torch.empty(B, Nk, nh * 64, device=q.device, dtype=q.dtype)
+    dv = torch.empty_like(dk)
+    delta = torch.empty(B, nh, Nq, device=q.device, dtype=torch.float32)
+    dsp = torch.zeros(2, device=q.device, dtype=torch.float32) if dists is not None else None
+    bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
+    _lib.check(lib.dsrg_attention_bwd(
+        _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
+        _p(do), bs(do), do.stride(1), _p(lse), _p(kmask), mask_mode if kmask is not None else _lib.MASK_NONE, _p(dists),
+        _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), _dt(q), _stream()),
+        'dsrg_attention_bwd')
+    return dq, dk, dv, dsp
 
 
 def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):

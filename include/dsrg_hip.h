@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 1
+#define DSRG_ABI_VERSION 2
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -64,13 +64,14 @@ int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems /*host*/, int nproblem
  *   DSRG_MASK_PLUS1: + m·1.0 — the object self-encoder quirk, a bool mask ADDED to the scores
  *   (FT/vilmodel.py:711-712 -> :143).
  * pair_dists: fp32 [B,Nq,Nk] or NULL; sprel_w/sprel_b: device pointers to the two scalars of
- * sprel_linear; the bias w·d+b (FT/vilmodel.py:757-759, 462-463) is formed in the kernel. */
+ * sprel_linear; the bias w·d+b (FT/vilmodel.py:757-759, 462-463) is formed in the kernel.
+ * lse: fp32 [B,NH,Nq] or NULL; when given, the log-sum-exp of each score row is stored for dsrg_attention_bwd. */
 enum { DSRG_MASK_NONE = 0, DSRG_MASK_NEG10000 = 1, DSRG_MASK_NEGINF = 2, DSRG_MASK_PLUS1 = 3 };
 int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
                        const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
                        const uint8_t* kmask, int mask_mode, const float* pair_dists,
                        const float* sprel_w, const float* sprel_b,
-                       int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream);
+                       int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream);
 
 /* ---- LayerNorm over the last dim (wave reduction, fp32 statistics) -------------------------------
  * out = LN(x [+ residual]) * gamma + beta.  Replaces BertLayerNorm / nn.LayerNorm
@@ -151,6 +152,18 @@ int dsrg_colsum_acc(const void* in, int ld, float* out, int M, int N, int dtype,
  * ClsPrediction :623, tanh of BertPooler :279).  n elements, n % 4 == 0. */
 int dsrg_act_fwd(const void* z, void* y, int64_t n, int act, int dtype, void* stream);
 int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, int act, int dtype, void* stream);
+
+/* Attention backward: dQ, dK, dV (contiguous [B,N,NH*64], storage dtype) and, when pair_dists is given, the two
+ * gradients of sprel_linear accumulated with float atomics into dsprel[2] (zeroed by the caller).  Scores are
+ * recomputed from Q, K, V and the forward's lse; delta_ws is an fp32 [B,NH,Nq] workspace.  O / dO are the forward
+ * output and its gradient (strides like the forward). */
+int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                       const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                       const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                       const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                       const float* sprel_w, const float* sprel_b,
+                       void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
+                       int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream);
 
 /* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
  *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].

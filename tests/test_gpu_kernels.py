@@ -101,6 +101,41 @@ def test_attention(K, dtype, B, nh, Nq, Nk, mode, sprel):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [
+    (4, 12, 20, 80, 1, False), (4, 12, 38, 38, 1, False), (4, 12, 20, 20, 1, True), (3, 12, 36, 36, 2, False),
+    (3, 2, 108, 108, 3, False), (2, 12, 100, 250, 1, False), (3, 12, 1, 5, 0, False), (2, 2, 70, 130, 1, True),
+])
+def test_attention_bwd(K, dtype, B, nh, Nq, Nk, mode, sprel):
+    """dsrg_attention_bwd (recompute from the forward's log-sum-exp) against torch autograd of the fp32 reference."""
+    H = nh * 64
+    if Nq == Nk:
+        qkv = _r(B, Nq, 3 * H, dtype=dtype)
+        q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
+    else:
+        q, kv = _r(B, Nq, H, dtype=dtype), _r(B, Nk, 2 * H, seed=1, dtype=dtype)
+        k, v = kv[..., :H], kv[..., H:]
+    lens = torch.randint(1, Nk + 1, (B,), generator=torch.Generator().manual_seed(5)); lens[0] = Nk
+    kmask = (torch.arange(Nk)[None] < lens[:, None]).cuda() if mode else None
+    dists = (_r(B, Nq, Nk, seed=7).abs() * 5) if sprel else None
+    sw, sb = (torch.tensor([-0.21]).cuda(), torch.tensor([0.07]).cuda()) if sprel else (None, None)
+    do = _r(B, Nq, H, seed=11, dtype=dtype)
+    out, lse = K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, want_lse=True)
+    dq, dk, dv, dsp = K.attention_bwd(q, k, v, out, do, lse, nh, kmask, mode, dists, sw, sb)
+    leaves = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    sp = [t.clone().requires_grad_(True) for t in (sw, sb)] if sprel else [None, None]
+    ref = _attn_ref(*leaves, nh, kmask, mode, dists, *sp)
+    ref.backward(do.float())
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    for name, got, want in (('dq', dq, leaves[0].grad), ('dk', dk, leaves[1].grad), ('dv', dv, leaves[2].grad)):
+        err = (got.float() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        assert err <= tol, (name, err)
+    if sprel:
+        want = torch.cat([sp[0].grad, sp[1].grad])
+        # d(sprel_b) is analytically 0 (a constant shift of a softmax row); judge both against the size of d(sprel_w)
+        assert ((dsp - want).abs().max() / want.abs().max().clamp_min(1.0)).item() <= (1e-3 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('H', [768, 128])
 def test_layernorm_and_embed(K, dtype, H):
     M = 777
