@@ -127,7 +127,7 @@ def gemm_roofline(model, runner, dtype):
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / rep
-        d = by_tile.setdefault(rec['tile'], {'flops': 0.0, 'time': 0.0, 'launches': 0})
+        d = by_tile.setdefault((rec['tile'][0], rec['tile'][1], rec['odt']), {'flops': 0.0, 'time': 0.0, 'launches': 0})
         d['flops'] += rec['flops']; d['time'] += t; d['launches'] += 1
     dom = max(by_tile, key=lambda k: by_tile[k]['time'])
     d = by_tile[dom]
@@ -135,7 +135,7 @@ def gemm_roofline(model, runner, dtype):
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
     return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
             'frac': d['flops'] / d['time'] / peak, 'traffic': None,
-            'kernel': 'gemm_nt_kernel<%s,%dx%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', dom[0], dom[1]),
+            'kernel': 'gemm_nt_kernel<%s,%s,%d,%d,2>' % ('bf16' if dtype == torch.bfloat16 else 'f32', 'f32' if dom[2] == 0 else 'bf16', dom[0], dom[1]),
             'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
             'all_gemm_us_per_step': tot_t * 1e6}

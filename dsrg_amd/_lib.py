@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get('DSRG_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libdsr
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
+IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
 ABI_VERSION = 2
 
@@ -17,6 +18,11 @@ class GemmProblem(C.Structure):
     _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p),
                 ('C', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
                 ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32)]
+
+
+class LnProblem(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('out', C.c_void_p),
+                ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -30,8 +36,9 @@ SIGNATURES = {
     'dsrg_attention_bwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
-    'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F,
-                                    _P, _I, _I, _I, _I, _P]),
+    'dsrg_layernorm_fwd_grouped': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _P]),
+    'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
+                                    _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),

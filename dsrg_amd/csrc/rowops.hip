@@ -47,84 +47,122 @@ __device__ __forceinline__ void ln_row(float4 (&v)[NV], int nv, int lane, int H,
     }
 }
 
+struct LnArgs {
+  dsrg_ln_problem_t p[DSRG_MAX_GROUPS];
+  int blk_start[DSRG_MAX_GROUPS + 1];     // first workgroup of each problem (WPB rows per workgroup)
+  int nprob, H;
+  float eps;
+};
+
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int ldx, const TO* __restrict__ res, int ldr,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        TO* __restrict__ out, int ldo, int M, int H, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int nv = (H + 255) / 256;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
+    if (i < a.nprob && (int)blockIdx.x >= a.blk_start[i]) g = i;
+  const dsrg_ln_problem_t& P = a.p[g];
+  const int row = ((int)blockIdx.x - a.blk_start[g]) * WPB + (threadIdx.x >> 6);
+  if (row >= P.M) return;
+  const TI* __restrict__ x = reinterpret_cast<const TI*>(P.x);
+  const TO* __restrict__ res = reinterpret_cast<const TO*>(P.residual);
+  TO* __restrict__ out = reinterpret_cast<TO*>(P.out);
+  const int H = a.H, nv = (H + 255) / 256;
   float4 v[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (i < nv && c < H) {
-      v[i] = ld4(x + (size_t)row * ldx + c);
-      if (res) v[i] = f4add(v[i], ld4(res + (size_t)row * ldr + c));
+      v[i] = ld4(x + (size_t)row * P.ldx + c);
+      if (res) v[i] = f4add(v[i], ld4(res + (size_t)row * P.ldr + c));
     }
   }
-  ln_row<MAXV>(v, nv, lane, H, gamma, beta, eps);
+  ln_row<MAXV>(v, nv, lane, H, P.gamma, P.beta, a.eps);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) st4(out + (size_t)row * ldo + c, v[i]);
+    if (i < nv && c < H) st4(out + (size_t)row * P.ldo + c, v[i]);
   }
 }
 
+struct EmbedIdx { const void* p; int kind, stride, div; };
 struct EmbedArgs {
   const void* base; int ldb;
   const float* feat; int ldf; int F;
   const float* Wf; const float* bf; const float* lnf_g; const float* lnf_b;
-  const float* E1; const int32_t* idx1; const float* E2; const int32_t* idx2;
+  const float* E1; EmbedIdx i1; const float* E2; EmbedIdx i2;
   const float* vec; const float* lno_g; const float* lno_b;
   float eps; void* out; int ldo; int M; int H;
 };
 
+__device__ __forceinline__ int embed_index(const EmbedIdx& ix, int row) {
+  const size_t o = (size_t)(row / ix.div) * ix.stride;
+  if (ix.kind == DSRG_IDX_I32) return reinterpret_cast<const int32_t*>(ix.p)[o];
+  if (ix.kind == DSRG_IDX_I64) return (int)reinterpret_cast<const int64_t*>(ix.p)[o];
+  return (int)reinterpret_cast<const float*>(ix.p)[o];      // class id carried as a float feature column
+}
+
+// 16 waves per workgroup, one row per wave.  The feature projection Wf [H,F] (F <= 16) is staged once per workgroup,
+// transposed, in LDS (WT[k][h], rows padded by 4 floats) so that a lane's 4 output columns are one ds_read_b128 per k.
+// The step is latency-bound (a few KB per row), so every independent global load of the row - features, indices,
+// base row, both table rows - is issued before the staging barrier and the row's arithmetic starts with all of
+// them in flight.
+constexpr int EWAVES = 16;
+
 template <typename T>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * WPB + (threadIdx.x >> 6);
-  if (row >= a.M) return;
-  const int H = a.H, nv = (H + 255) / 256;
+__global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float WT[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, nv = (H + 255) / 256, HS = H + 4;
+  const int row = blockIdx.x * EWAVES + wave;
+  const bool live = row < a.M;
+  const T* base = reinterpret_cast<const T*>(a.base);
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) f[k] = (live && a.feat && k < a.F) ? a.feat[(size_t)row * a.ldf + k] : 0.f;
+  const int i1 = (live && a.E1) ? embed_index(a.i1, row) : 0, i2 = (live && a.E2) ? embed_index(a.i2, row) : 0;
+  float4 add[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    add[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && i < nv && c < H) {
+      if (base) add[i] = ld4(base + (size_t)row * a.ldb + c);
+      if (a.E1) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c));
+      if (a.E2) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c));
+      if (a.vec) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.vec + c));
+    }
+  }
+  if (a.feat) {
+    for (int j = threadIdx.x; j < H * a.F; j += 64 * EWAVES) {
+      const int h = j / a.F, k = j - h * a.F;
+      WT[k * HS + h] = a.Wf[j];
+    }
+    __syncthreads();
+  }
+  if (!live) return;
   float4 v[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.feat) {
-    float f[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) f[k] = (k < a.F) ? a.feat[(size_t)row * a.ldf + k] : 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
-        float o[4];
+        float4 o = a.bf ? *reinterpret_cast<const float4*>(a.bf + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float* w = a.Wf + (size_t)(c + e) * a.F;
-          float s = 0.f;
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            if (k < a.F) s = fmaf(w[k], f[k], s);
-          o[e] = s + (a.bf ? a.bf[c + e] : 0.f);
-        }
-        v[i] = make_float4(o[0], o[1], o[2], o[3]);
+        for (int k = 0; k < 16; ++k)
+          if (k < a.F) {
+            const float4 w = *reinterpret_cast<const float4*>(&WT[k * HS + c]);
+            o.x = fmaf(w.x, f[k], o.x); o.y = fmaf(w.y, f[k], o.y); o.z = fmaf(w.z, f[k], o.z); o.w = fmaf(w.w, f[k], o.w);
+          }
+        v[i] = o;
       }
     }
     if (a.lnf_g) ln_row<MAXV>(v, nv, lane, H, a.lnf_g, a.lnf_b, a.eps);
   }
-  const T* base = reinterpret_cast<const T*>(a.base);
-  const int i1 = a.E1 ? a.idx1[row] : 0, i2 = a.E2 ? a.idx2[row] : 0;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) {
-      if (base) v[i] = f4add(ld4(base + (size_t)row * a.ldb + c), v[i]);
-      if (a.E1) v[i] = f4add(v[i], *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c));
-      if (a.E2) v[i] = f4add(v[i], *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c));
-      if (a.vec) v[i] = f4add(v[i], *reinterpret_cast<const float4*>(a.vec + c));
-    }
-  }
+  for (int i = 0; i < MAXV; ++i) v[i] = f4add(add[i], v[i]);
   if (a.lno_g) ln_row<MAXV>(v, nv, lane, H, a.lno_g, a.lno_b, a.eps);
   T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
@@ -146,21 +184,41 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const T* __restrict__ x
   st4(out + (size_t)m * ldo + c, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
 }
 
-// one block per episode; wave w scores views w, w+4, ...; then all threads form the weighted sum
+// One 1024-thread workgroup per episode, every view row read from HBM exactly once: wave w loads views w, w+16, ..
+// (all loads issued before anything depends on them), scores them, and after the softmax over the LDS score vector
+// forms the weighted sum of ITS OWN rows from registers; the 16 partial sums are combined through LDS.
+constexpr int GWAVES = 16, GVPW = 4;      // V <= 64
 template <typename T>
-__global__ __launch_bounds__(256) void gaa_pool_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                       T* __restrict__ out, int V, int H) {
+__global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, int V, int H) {
   __shared__ float sc[64];
+  extern __shared__ __attribute__((aligned(16))) float part[];     // [GWAVES][H]
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (H + 255) / 256;
   const T* xb = x + (size_t)b * V * H;
-  for (int v = wave; v < V; v += 4) {
-    float s = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      float4 a = ld4(xb + (size_t)v * H + c), ww = *reinterpret_cast<const float4*>(w + c);
-      s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+  float4 row[GVPW][MAXV];
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = wave + GWAVES * r, c = (i * 64 + lane) * 4;
+      row[r][i] = (v < V && i < nv && c < H) ? ld4(xb + (size_t)v * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  float4 ww[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    ww[i] = (i < nv && c < H) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float b0 = bias[0];
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r) {
+    const int v = wave + GWAVES * r;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s += row[r][i].x * ww[i].x + row[r][i].y * ww[i].y + row[r][i].z * ww[i].z + row[r][i].w * ww[i].w;
     s = wave_sum(s);
-    if (lane == 0) sc[v] = tanhf(s + bias[0]);
+    if (lane == 0 && v < V) sc[v] = tanhf(s + b0);
   }
   __syncthreads();
   float mx = -INFINITY;
@@ -168,14 +226,30 @@ __global__ __launch_bounds__(256) void gaa_pool_kernel(const T* __restrict__ x, 
   float den = 0.f;
   for (int v = 0; v < V; ++v) den += expf(sc[v] - mx);
   const float inv = 1.0f / den;
-  for (int c = threadIdx.x * 4; c < H; c += 1024) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int v = 0; v < V; ++v) {
-      const float p = expf(sc[v] - mx) * inv;
-      float4 a = ld4(xb + (size_t)v * H + c);
-      acc.x += a.x * p; acc.y += a.y * p; acc.z += a.z * p; acc.w += a.w * p;
+  float4 acc[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r) {
+    const int v = wave + GWAVES * r;
+    const float p = v < V ? expf(sc[v] - mx) * inv : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      acc[i].x += row[r][i].x * p; acc[i].y += row[r][i].y * p; acc[i].z += row[r][i].z * p; acc[i].w += row[r][i].w * p;
     }
-    st4(out + (size_t)b * H + c, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (i < nv && c < H) *reinterpret_cast<float4*>(&part[wave * H + c]) = acc[i];
+  }
+  __syncthreads();
+  const int c = threadIdx.x * 4;
+  if (c < H) {
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < GWAVES; ++g) sum = f4add(sum, *reinterpret_cast<const float4*>(&part[g * H + c]));
+    st4(out + (size_t)b * H + c, sum);
   }
 }
 
@@ -280,46 +354,79 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta,
-                                  void* out, int ldo, int M, int H, float eps, int in_dtype, int out_dtype, void* stream) {
+extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
+                                          int out_dtype, void* stream) {
+  DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS, "dsrg_layernorm_fwd: nproblems=%d out of [1,%d]", nproblems,
+             DSRG_MAX_GROUPS);
   DSRG_CHECK(ok_dtype(in_dtype) && ok_dtype(out_dtype), "dsrg_layernorm_fwd: bad dtype");
-  DSRG_CHECK(in_dtype == DSRG_F32 || in_dtype == out_dtype, "dsrg_layernorm_fwd: in_dtype must be f32 or equal out_dtype");
-  DSRG_CHECK(x && gamma && beta && out && M >= 0, "dsrg_layernorm_fwd: null argument");
+  DSRG_CHECK(in_dtype == DSRG_F32 || in_dtype == out_dtype, "dsrg_layernorm_fwd: input must be f32 or the output dtype");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_layernorm_fwd: H=%d must be a multiple of 64 and <= 1024", H);
-  DSRG_CHECK(ldx % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0) && ldx >= H && ldo >= H, "dsrg_layernorm_fwd: bad leading dims");
-  DSRG_CHECK(al16(x) && al16(out) && al16(gamma) && al16(beta) && ((uintptr_t)residual & 7) == 0, "dsrg_layernorm_fwd: misaligned pointer");
-  if (M == 0) return DSRG_OK;
+  LnArgs a;
+  a.nprob = 0; a.H = H; a.eps = eps;
+  int blocks = 0;
+  for (int i = 0; i < nproblems; ++i) {
+    const dsrg_ln_problem_t& p = problems[i];
+    DSRG_CHECK(p.M >= 0, "dsrg_layernorm_fwd: problem %d has M < 0", i);
+    if (p.M == 0) continue;
+    DSRG_CHECK(p.x && p.gamma && p.beta && p.out, "dsrg_layernorm_fwd: problem %d has a null pointer", i);
+    DSRG_CHECK(p.ldx % 4 == 0 && p.ldo % 4 == 0 && (!p.residual || p.ldr % 4 == 0) && p.ldx >= H && p.ldo >= H && (!p.residual || p.ldr >= H),
+               "dsrg_layernorm_fwd: problem %d leading dims must be >= H and multiples of 4", i);
+    DSRG_CHECK(al16(p.gamma) && al16(p.beta) && ((uintptr_t)p.x & 7) == 0 && ((uintptr_t)p.out & 7) == 0 && ((uintptr_t)p.residual & 7) == 0 &&
+                   (in_dtype == DSRG_BF16 || al16(p.x)) && (out_dtype == DSRG_BF16 || (al16(p.out) && al16(p.residual))),
+               "dsrg_layernorm_fwd: problem %d has a misaligned pointer", i);
+    a.blk_start[a.nprob] = blocks;
+    a.p[a.nprob++] = p;
+    blocks += (p.M + WPB - 1) / WPB;
+  }
+  if (a.nprob == 0) return DSRG_OK;
+  a.blk_start[a.nprob] = blocks;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((M + WPB - 1) / WPB), block(256);
-  if (in_dtype == DSRG_F32 && out_dtype == DSRG_F32)
-    hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, ldx, (const float*)residual, ldr, gamma, beta, (float*)out, ldo, M, H, eps);
-  else if (in_dtype == DSRG_F32)
-    hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, M, H, eps);
-  else
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, M, H, eps);
+  dim3 grid(blocks), block(256);
+  if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, a);
+  else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
   DSRG_LAUNCH_CHECK("dsrg_layernorm_fwd");
   return DSRG_OK;
 }
 
+extern "C" int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta,
+                                  void* out, int ldo, int M, int H, float eps, int in_dtype, int out_dtype, void* stream) {
+  const dsrg_ln_problem_t p{x, residual, gamma, beta, out, M, ldx, ldr, ldo};
+  return dsrg_layernorm_fwd_grouped(&p, 1, H, eps, in_dtype, out_dtype, stream);
+}
+
 extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, int ldf, int F, const float* Wf, const float* bf,
-                                 const float* lnf_gamma, const float* lnf_beta, const float* E1, const int32_t* idx1,
-                                 const float* E2, const int32_t* idx2, const float* vec, const float* lno_gamma,
-                                 const float* lno_beta, float eps, void* out, int ldo, int M, int H, int dtype, void* stream) {
+                                 const float* lnf_gamma, const float* lnf_beta,
+                                 const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                                 const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                                 const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                                 void* out, int ldo, int M, int H, int dtype, void* stream) {
   DSRG_CHECK(ok_dtype(dtype), "dsrg_embed_ln_fwd: bad dtype %d", dtype);
   DSRG_CHECK(out && M >= 0, "dsrg_embed_ln_fwd: null out");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_embed_ln_fwd: H=%d must be a multiple of 64 and <= 1024", H);
   DSRG_CHECK(!feat || (Wf && F >= 1 && F <= 16 && ldf >= F), "dsrg_embed_ln_fwd: feature term needs Wf and 1 <= F <= 16");
   DSRG_CHECK((!E1 || idx1) && (!E2 || idx2), "dsrg_embed_ln_fwd: embedding table without indices");
+  DSRG_CHECK((!E1 || (idx1_kind >= DSRG_IDX_I32 && idx1_kind <= DSRG_IDX_F32 && idx1_stride >= 1 && idx1_div >= 1)) &&
+                 (!E2 || (idx2_kind >= DSRG_IDX_I32 && idx2_kind <= DSRG_IDX_F32 && idx2_stride >= 1 && idx2_div >= 1)),
+             "dsrg_embed_ln_fwd: bad index kind / stride / div");
   DSRG_CHECK((!lnf_gamma || lnf_beta) && (!lno_gamma || lno_beta), "dsrg_embed_ln_fwd: LayerNorm gamma without beta");
   DSRG_CHECK(ldo % 4 == 0 && ldo >= H && (!base || (ldb % 4 == 0 && ldb >= H)), "dsrg_embed_ln_fwd: bad leading dims");
   DSRG_CHECK(al16(out) && ((uintptr_t)base & 7) == 0 && al16(E1) && al16(E2) && al16(vec) && al16(lno_gamma) && al16(lno_beta) &&
-                 al16(lnf_gamma) && al16(lnf_beta), "dsrg_embed_ln_fwd: misaligned pointer");
+                 al16(lnf_gamma) && al16(lnf_beta) && al16(bf), "dsrg_embed_ln_fwd: misaligned pointer");
   if (M == 0) return DSRG_OK;
-  EmbedArgs a{base, ldb, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, idx1, E2, idx2, vec, lno_gamma, lno_beta, eps, out, ldo, M, H};
+  EmbedArgs a{base, ldb, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, {idx1, idx1_kind, idx1_stride, idx1_div},
+              E2, {idx2, idx2_kind, idx2_stride, idx2_div}, vec, lno_gamma, lno_beta, eps, out, ldo, M, H};
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((M + WPB - 1) / WPB), block(256);
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_kernel<float>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((embed_ln_kernel<bf16_t>), grid, block, 0, s, a);
+  dim3 grid((M + EWAVES - 1) / EWAVES), block(64 * EWAVES);
+  const size_t lds = feat ? (size_t)F * (H + 4) * sizeof(float) : 0;     // <= 16 * 1028 * 4 = 65,792 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
+    attr_set = true;
+  }
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_kernel<float>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((embed_ln_kernel<bf16_t>), grid, block, lds, s, a);
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_fwd");
   return DSRG_OK;
 }
@@ -339,12 +446,18 @@ extern "C" int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, i
 
 extern "C" int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* out, int B, int V, int H, int dtype, void* stream) {
   DSRG_CHECK(ok_dtype(dtype) && x && w && bias && out, "dsrg_gaa_pool_fwd: bad dtype or null pointer");
-  DSRG_CHECK(V >= 1 && V <= 64 && H > 0 && H % 4 == 0, "dsrg_gaa_pool_fwd: need 1 <= V <= 64 (got %d) and H %% 4 == 0", V);
+  DSRG_CHECK(V >= 1 && V <= 64 && H > 0 && H % 4 == 0 && H <= 1024, "dsrg_gaa_pool_fwd: need 1 <= V <= 64 (got %d), H %% 4 == 0 and H <= 1024", V);
   DSRG_CHECK(al16(x) && al16(out) && al16(w), "dsrg_gaa_pool_fwd: misaligned pointer");
   if (B <= 0) return DSRG_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)x, w, bias, (float*)out, V, H);
-  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)x, w, bias, (bf16_t*)out, V, H);
+  static bool attr_set = false;
+  if (!attr_set) {     // 16 x 1024 floats + the score vector is just over the 64 KiB default
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gaa_pool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gaa_pool_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, w, bias, (float*)out, V, H);
+  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, w, bias, (bf16_t*)out, V, H);
   DSRG_LAUNCH_CHECK("dsrg_gaa_pool_fwd");
   return DSRG_OK;
 }

@@ -203,11 +203,11 @@ class _LinearLNFn(torch.autograd.Function):
                     m = (torch.rand_like(z) >= p_drop).to(z.dtype).mul_(1.0 / (1.0 - p_drop))
                     z.mul_(m)
                     masks.append(m.to(probs[0][1].dtype))
-                ys = [K.layernorm(z, p[4], p[5], eps, p[3], p[1].dtype) for z, p in zip(zs, probs)]
+                ys = K.layernorm_grouped([(z, p[4], p[5], p[3]) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
             else:
                 masks = [None] * n
                 zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in probs], ACT_NONE, True)
-                ys = [K.layernorm(z, p[4], p[5], eps, None, p[1].dtype) for z, p in zip(zs, probs)]
+                ys = K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
         ctx.drop = p_drop > 0
         ctx.hasr = [p[3] is not None for p in probs]
         ctx.hasb = [p[2] is not None for p in probs]
@@ -254,7 +254,7 @@ def linear_ln_grouped(problems, eps, p_drop=0.0):
     flat = [t for p in problems for t in p]
     if not _needs_grad(flat) and p_drop == 0.0:
         zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in problems], ACT_NONE, True)
-        return [K.layernorm(z, p[4], p[5], eps, None, p[1].dtype) for z, p in zip(zs, problems)]
+        return K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, problems)], eps, problems[0][1].dtype)
     return list(_LinearLNFn.apply(len(problems), eps, float(p_drop), *flat))
 
 
@@ -313,6 +313,13 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
 
 
 # ----------------------------------------------------------------------------- token embedding
+def _rows_index(idx, M):
+    """embed_ln index operand (tensor or (tensor, div)) -> int64 [M]"""
+    t, div = idx if isinstance(idx, tuple) else (idx, 1)
+    t = t.long()
+    return t if div == 1 else t.repeat_interleave(div)[:M]
+
+
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
              E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
@@ -330,9 +337,9 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
         if base is not None:
             z = z + base.reshape(M, H).float()
         if E1 is not None:
-            z = z + E1[idx1.long()]
+            z = z + E1[_rows_index(idx1, M)]
         if E2 is not None:
-            z = z + E2[idx2.long()]
+            z = z + E2[_rows_index(idx2, M)]
         if vec is not None:
             z = z + vec
         if lno_g is not None:

@@ -165,6 +165,43 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
     return out
 
 
+def layernorm_grouped(problems, eps, out_dtype=None):
+    """problems: list of (x, gamma, beta, residual|None) with one H and one input dtype -> list of outputs, ONE launch."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= _lib.MAX_GROUPS:
+        raise _lib.DsrgHipError('layernorm_grouped: %d problems (max %d)' % (n, _lib.MAX_GROUPS))
+    x0 = problems[0][0]
+    _dev(x0)
+    H = x0.shape[-1]
+    out_dtype = out_dtype or (problems[0][3].dtype if problems[0][3] is not None else x0.dtype)
+    arr = (_lib.LnProblem * n)()
+    outs = []
+    for i, (x, g, b, r) in enumerate(problems):
+        if x.shape[-1] != H or x.dtype != x0.dtype:
+            raise _lib.DsrgHipError('layernorm_grouped: problems must share H and dtype')
+        M, ldx = _rows(x)
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        outs.append(out)
+        arr[i].x, arr[i].residual, arr[i].gamma, arr[i].beta, arr[i].out = _p(x), _p(r), _p(g), _p(b), _p(out)
+        arr[i].M, arr[i].ldx, arr[i].ldr, arr[i].ldo = M, ldx, (_rows(r)[1] if r is not None else 0), _rows(out)[1]
+    _lib.check(lib.dsrg_layernorm_fwd_grouped(arr, n, H, float(eps), _dt(x0), _dt(outs[0]), _stream()), 'dsrg_layernorm_fwd_grouped')
+    return outs
+
+
+def _idx(t, M, what):
+    """index operand of embed_ln -> (ptr, kind, stride, div).  `t` is a tensor (int32 / int64 / float32, 1-D, any
+    stride) with M entries, or a tuple (tensor, div) with ceil(M / div) entries: row r uses entry r // div."""
+    if t is None:
+        return None, 0, 1, 1
+    t, div = t if isinstance(t, tuple) else (t, 1)
+    kind = {torch.int32: _lib.IDX_I32, torch.int64: _lib.IDX_I64, torch.float32: _lib.IDX_F32}.get(t.dtype)
+    if kind is None or t.dim() != 1 or t.numel() * div < M or div < 1 or (t.numel() > 1 and t.stride(0) < 1):
+        raise _lib.DsrgHipError('embed_ln: %s must be a 1-D int32/int64/float32 tensor covering %d rows' % (what, M))
+    _dev(t)
+    return t, kind, (t.stride(0) if t.numel() > 1 else 1), div
+
+
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
              E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
     lib = _lib.load()
@@ -174,15 +211,16 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
     ldo = _rows(out)[1]
     ldb = _rows(base)[1] if base is not None else 0
     F_, ldf = (feat.shape[-1], _rows(feat)[1]) if feat is not None else (0, 0)
-    for t in (idx1, idx2):
-        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
-            raise _lib.DsrgHipError('embed_ln: indices must be contiguous int32')
+    if feat is not None and feat.dtype != torch.float32:
+        raise _lib.DsrgHipError('embed_ln: feat must be fp32')
+    i1, k1, s1, d1 = _idx(idx1 if E1 is not None else None, M, 'idx1')
+    i2, k2, s2, d2 = _idx(idx2 if E2 is not None else None, M, 'idx2')
     if base is not None and base.dtype != out.dtype:
         raise _lib.DsrgHipError('embed_ln: base dtype must match out dtype')
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
     _lib.check(lib.dsrg_embed_ln_fwd(_p(base), ldb, _p(feat), ldf, F_, _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b),
-                                     _p(E1), _p(idx1), _p(E2), _p(idx2), _p(vec), _p(lno_g), _p(lno_b),
+                                     _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),
                                      float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd')
     return out
 

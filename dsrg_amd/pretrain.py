@@ -76,7 +76,7 @@ class GlocalTextPathCMT(_Backbone):
         img = torch.zeros(B * G, H, device=dev, dtype=torch.float32).index_add_(0, torch.from_numpy(dst).to(dev), rows).to(cd)
         g = Fn.embed_ln(B * G, H, cd, dev, base=img, feat=b['gmap_pos_fts'].float().reshape(B * G, -1).contiguous(),
                         Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'], lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']),
-                        E1=W['gmap.step'], idx1=b['gmap_step_ids'].reshape(-1).to(torch.int32).contiguous()).view(B, G, H)
+                        E1=W['gmap.step'], idx1=b['gmap_step_ids'].reshape(-1)).view(B, G, H)
         gmask = (torch.arange(G, device=dev)[None] < b['gmap_lens'][:, None]).contiguous()
         return g, gmask
 

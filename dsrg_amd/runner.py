@@ -23,7 +23,12 @@ class GraphedNavStep:
         if 'gmap_src' not in self.nav:
             src, bw = model.fusion_indices(self.nav['gmap_vpids'], self.nav['gmap_visited_masks'], self.nav['vp_cand_vpids'], G, Vp)
             self.nav['gmap_src'], self.nav['bw_mask'] = torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev)
-        self.mem = torch.zeros(B, model.config.hidden_size, device=dev, dtype=model.compute_dtype)
+        H, cd = model.config.hidden_size, model.compute_dtype
+        # static compute-dtype token buffers of the navigation call: slot 1 = [MEM] (fed back from cls_embeds), graph-map
+        # slot 2 = the current node (GAA-pooled panorama), viewpoint slots 2.. = this step's panorama tokens
+        self.gmap_img = self.nav['gmap_img_embeds'].to(cd).clone()
+        self.vp_img = torch.zeros(B, Vp, H, device=dev, dtype=cd)
+        self.gmap_img[:, 1].zero_()
         with torch.no_grad():
             self.kv = model.text_kv(self.txt)
         self.out = None
@@ -45,21 +50,27 @@ class GraphedNavStep:
             self.txt.copy_(txt_embeds)
             self.txt_masks.copy_(txt_masks)
             self.model.text_kv(self.txt, out=self.kv)
-            self.mem.zero_()
+            self.gmap_img[:, 1].zero_()
+            self.vp_img[:, 1].zero_()
+
+    def set_gmap_img(self, gmap_img_embeds):
+        """New graph-map node embeddings (any float dtype); slots 1 and 2 are owned by the runner."""
+        with torch.no_grad():
+            mem = self.vp_img[:, 1].clone()
+            self.gmap_img.copy_(gmap_img_embeds)
+            self.gmap_img[:, 1] = mem
 
     def _body(self):
         m = self.model
         pe, pm, pf = m('panorama', self.pano)
         nb = dict(self.nav)
-        z = torch.zeros_like(pe[:, :1])
-        nb['vp_img_embeds'] = torch.cat([z, self.mem[:, None], pe], 1)
-        g = self.nav['gmap_img_embeds'].to(pe.dtype).clone()
-        g[:, 1] = self.mem
-        g[:, 2] = pf
-        nb['gmap_img_embeds'] = g
-        nb.update(txt_embeds=self.txt, txt_masks=self.txt_masks, txt_kv=self.kv)
+        self.vp_img[:, 2:] = pe
+        self.gmap_img[:, 2] = pf
+        nb.update(vp_img_embeds=self.vp_img, gmap_img_embeds=self.gmap_img,
+                  txt_embeds=self.txt, txt_masks=self.txt_masks, txt_kv=self.kv)
         o = m('navigation', nb)
-        self.mem.copy_(o['cls_embeds'])
+        self.vp_img[:, 1] = o['cls_embeds']
+        self.gmap_img[:, 1] = o['cls_embeds']
         self.out = {'pano_embeds': pe, 'pano_fused': pf, **o}
 
     def step(self):

@@ -105,8 +105,18 @@ def _img_embeddings(cfg, reverie):
     return m
 
 
-def _i32(t):
-    return t.to(torch.int32).contiguous()
+_ARANGE = {}
+
+
+def _arange(n, device):
+    """cached torch.arange(n) (the length masks are rebuilt every step; the ramp is a constant)"""
+    key = (n, str(device))
+    t = _ARANGE.get(key)
+    if t is None:
+        t = torch.arange(n, device=device)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):   # never cache graph-pool memory
+            _ARANGE[key] = t
+    return t
 
 
 class GlocalTextPathNavCMT(nn.Module):
@@ -351,7 +361,7 @@ class GlocalTextPathNavCMT(nn.Module):
         B, L = txt_ids.shape
         H, nh = cfg.hidden_size, cfg.num_attention_heads
         pos = torch.arange(L, device=txt_ids.device, dtype=torch.int32).repeat(B)
-        x = Fn.embed_ln(B * L, H, cd, txt_ids.device, E1=W['emb.word'], idx1=_i32(txt_ids.reshape(-1)),
+        x = Fn.embed_ln(B * L, H, cd, txt_ids.device, E1=W['emb.word'], idx1=txt_ids.reshape(-1),
                         E2=W['emb.pos'], idx2=pos, vec=W['emb.type'][0], lno=(W['emb.ln.g'], W['emb.ln.b']),
                         eps=cfg.layer_norm_eps).view(B, L, H)
         x = self._drop(x, cfg.hidden_dropout_prob)
@@ -383,10 +393,10 @@ class GlocalTextPathNavCMT(nn.Module):
         d = cfg.obj_v2_size
         fts = fts.float().contiguous()
         e = Fn.embed_ln(B * V * O, d, cd, fts.device, feat=fts.view(B * V * O, -1)[:, :-1], Wf=W['obj.bbox.w'],
-                        bf=W['obj.bbox.b'], E1=W['obj.name'], idx1=_i32(fts[..., -1].reshape(-1)),
-                        E2=W['obj.nav'], idx2=_i32(nav_types.reshape(-1).repeat_interleave(O)),
+                        bf=W['obj.bbox.b'], E1=W['obj.name'], idx1=fts.view(B * V * O, -1)[:, -1],
+                        E2=W['obj.nav'], idx2=(nav_types.reshape(-1), O),
                         lno=(W['obj.ln.g'], W['obj.ln.b'])).view(B, V * O, d)
-        valid = (torch.arange(O, device=fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
+        valid = (_arange(O, fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
         for i in range(2):
             e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
         return e.reshape(B * V * O, d), O
@@ -417,7 +427,7 @@ class GlocalTextPathNavCMT(nn.Module):
         B, T, H = base.shape
         x = Fn.embed_ln(B * T, H, self.compute_dtype, base.device, base=base.reshape(B * T, H),
                         feat=loc_fts.float().reshape(B * T, -1).contiguous(), Wf=W['loc.w'], bf=W['loc.b'],
-                        lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=_i32(nav_types.reshape(-1)),
+                        lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=nav_types.reshape(-1),
                         vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b'])).view(B, T, H)
         return self._drop(x, getattr(cfg, 'image_dropout_prob', cfg.hidden_dropout_prob) if self.REVERIE else cfg.hidden_dropout_prob)
 
@@ -437,7 +447,7 @@ class GlocalTextPathNavCMT(nn.Module):
         img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
         obj_rows, O = self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types)
         x = self._pano_tokens(W, img, loc_fts, nav_types)
-        pano_masks = torch.arange(V, device=x.device)[None] < view_lens[:, None]
+        pano_masks = _arange(V, x.device)[None] < view_lens[:, None]
         x = self._pano_encoder(W, x, pano_masks.contiguous())
         g, b = W['pano.norm.g'], W['pano.norm.b']
         cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
@@ -545,7 +555,7 @@ class GlocalTextPathNavCMT(nn.Module):
         g = Fn.embed_ln(B * G, H, cd, dev, base=gmap_img_embeds.to(cd).reshape(B * G, H),
                         feat=gmap_pos_fts.float().reshape(B * G, -1).contiguous(), Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'],
                         lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']), E1=W['gmap.step'],
-                        idx1=_i32(gmap_step_ids.reshape(-1))).view(B, G, H)
+                        idx1=gmap_step_ids.reshape(-1)).view(B, G, H)
         v = Fn.embed_ln(B * Vp, H, cd, dev, base=vp_img_embeds.to(cd).reshape(B * Vp, H),
                         feat=vp_pos_fts.float().reshape(B * Vp, -1).contiguous(), Wf=W['vp.pos.w'], bf=W['vp.pos.b'],
                         lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)

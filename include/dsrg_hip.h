@@ -82,6 +82,19 @@ int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, co
                        const float* beta, void* out, int ldo, int M, int H, float eps, int in_dtype,
                        int out_dtype, void* stream);
 
+/* The same over up to DSRG_MAX_GROUPS independent row sets in ONE launch (the global and local branch of a
+ * CrossmodalEncoder layer normalise at the same point, FT/vilmodel.py:540-549; a launch costs more than the rows). */
+typedef struct {
+  const void* x;        /* [M,H] rows, leading dim ldx */
+  const void* residual; /* NULL or [M,H], leading dim ldr */
+  const float* gamma;
+  const float* beta;
+  void* out;            /* [M,H], leading dim ldo */
+  int32_t M, ldx, ldr, ldo;
+} dsrg_ln_problem_t;
+int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems /*host*/, int nproblems, int H, float eps,
+                               int in_dtype, int out_dtype, void* stream);
+
 /* ---- token embedding: sum of parts + LayerNorm ---------------------------------------------------
  * out[r,:] = LNo( base[r,:] + LNf( Wf·feat[r,:] + bf ) + E1[idx1[r],:] + E2[idx2[r],:] + vec[:] )
  * Every term is optional (NULL).  One kernel covers:
@@ -90,11 +103,16 @@ int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, co
  *   panorama tokens (img + LN(loc_linear) + nav_type + token_type[1] -> LN), :719-723;
  *   graph-map tokens (img + step embedding + LN(Linear(7))), :753-755;
  *   viewpoint tokens (img + LN(Linear(14))), :769.
- * feat is fp32 [M,F] (ldf), F <= 16; Wf is fp32 [H,F]; E1/E2/vec/gammas/betas fp32; base/out `dtype`.
- * lnf_* NULL => no LayerNorm on the feature term; lno_* NULL => no output LayerNorm. */
+ * feat is fp32 [M,F] (ldf), F <= 16; Wf is fp32 [H,F] (the nn.Linear layout); E1/E2/vec/gammas/betas fp32;
+ * base/out `dtype`.  lnf_* NULL => no LayerNorm on the feature term; lno_* NULL => no output LayerNorm.
+ * Row r takes table index idx[(r / div) * stride], read as int32, int64 or as a float that carries a class id
+ * (the reference keeps the object class in the last feature column, :701, and repeats the per-view nav type over
+ * the view's objects, :703-705) - so no index tensor has to be converted or expanded before the call. */
+enum { DSRG_IDX_I32 = 0, DSRG_IDX_I64 = 1, DSRG_IDX_F32 = 2 };
 int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, int ldf, int F, const float* Wf,
                       const float* bf, const float* lnf_gamma, const float* lnf_beta,
-                      const float* E1, const int32_t* idx1, const float* E2, const int32_t* idx2,
+                      const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                      const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
                       const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
                       void* out, int ldo, int M, int H, int dtype, void* stream);
 

@@ -160,6 +160,19 @@ def test_layernorm_and_embed(K, dtype, H):
     out = K.embed_ln(M, H, dtype, 'cuda', feat=feat8[:, :F_], Wf=Wf, bf=bf, E1=E1, idx1=i1)
     ref = feat8[:, :F_] @ Wf.T + bf + E1[i1.long()]
     assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 3e-2)
+    # index operands as the reference holds them: class id in the last (float) feature column, int64 ids, and one
+    # id per group of 3 rows (the view's nav type repeated over its objects); 14 features (viewpoint position)
+    feat8[:, -1] = i1.float()
+    i2g = torch.randint(0, 3, ((M + 2) // 3,)).cuda()
+    out = K.embed_ln(M, H, dtype, 'cuda', feat=feat8[:, :F_], Wf=Wf, bf=bf, E1=E1, idx1=feat8[:, -1], E2=E2, idx2=(i2g, 3),
+                     lno=(g, b))
+    ref = torch.nn.functional.layer_norm(feat8[:, :F_] @ Wf.T + bf + E1[i1.long()] + E2[i2g.repeat_interleave(3)[:M]], (H,), g, b, 1e-12)
+    assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 3e-2)
+    f14, W14 = _r(M, 14, seed=12), _r(H, 14, seed=13, scale=0.3)
+    out = K.embed_ln(M, H, dtype, 'cuda', base=base, feat=f14, Wf=W14, bf=bf, lnf=(g, b), E1=E1, idx1=i1.long())
+    ref = base.float() + torch.nn.functional.layer_norm(f14 @ W14.T + bf, (H,), g, b, 1e-12) + E1[i1.long()]
+    # no output LayerNorm here: values reach ~8, so the bf16 bound is half an ulp of the largest value
+    assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2.0 ** -8 * ref.abs().max().item())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
