@@ -106,6 +106,32 @@ def cpu_baseline(cfg, sd, lb, pb, nb, dims, budget_s=20.0):
                       % (it, B, torch.__version__, cores, dt)}
 
 
+def pmc_traffic(kernel_sig, grids):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch.csv,
+    *_pmc_write.csv; separate --pmc runs of this same bench, summarised by tools/pmc_summary.py).  FETCH_SIZE and
+    WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled (MI355X_MICROARCH.md,
+    HBM section).  Averaged over the launches of one step, matched by kernel template + grid size.  None if absent."""
+    import csv, glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    fetch, write = sorted(glob.glob(os.path.join(here, 'profiles', '*_pmc_fetch.csv'))), sorted(glob.glob(os.path.join(here, 'profiles', '*_pmc_write.csv')))
+    if not fetch or not write:
+        return None, None
+
+    def table(path, counter):
+        t = {}
+        for r in csv.DictReader(open(path)):
+            if r['Counter'] == counter and kernel_sig in r['Kernel']:
+                t[int(r['GridSize'])] = float(r['AvgValue'])
+        return t
+    f, w = table(fetch[-1], 'FETCH_SIZE'), table(write[-1], 'WRITE_SIZE')
+    tot = 0.0
+    for g in grids:
+        if g not in f or g not in w:
+            return None, None
+        tot += (2.0 * f[g] + w[g]) * 1024.0
+    return tot / len(grids), os.path.basename(fetch[-1])
+
+
 def gemm_roofline(model, runner, dtype):
     """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step, then re-issue
     each launch `rep` times back to back between HIP events on the launch stream; achieved = algorithmic FLOPs of the
@@ -127,14 +153,21 @@ def gemm_roofline(model, runner, dtype):
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / rep
-        d = by_tile.setdefault((rec['tile'][0], rec['tile'][1], rec['odt']), {'flops': 0.0, 'time': 0.0, 'launches': 0})
-        d['flops'] += rec['flops']; d['time'] += t; d['launches'] += 1
+        d = by_tile.setdefault((rec['tile'][0], rec['tile'][1], rec['odt']), {'flops': 0.0, 'time': 0.0, 'launches': 0, 'grids': [], 'bytes': 0.0})
+        d['flops'] += rec['flops']; d['time'] += t; d['launches'] += 1; d['grids'].append(rec['wgs'] * 256)
+        esz, osz = (2 if rec['dt'] == 1 else 4), (4 if rec['odt'] == 0 else 2)
+        d['bytes'] += sum((a.M * a.K + a.N * a.K) * esz + a.M * a.N * osz + (a.M * a.N * esz if a.residual else 0) for a in rec['arr'])
     dom = max(by_tile, key=lambda k: by_tile[k]['time'])
     d = by_tile[dom]
     peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
+    sig = 'gemm_nt_kernel<%s, %s, %d, %d, 2>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
+                                                  'float' if dom[2] == 0 else 'unsigned short', dom[0], dom[1])
+    traffic, src = pmc_traffic(sig, d['grids'])
     return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-            'frac': d['flops'] / d['time'] / peak, 'traffic': None,
+            'frac': d['flops'] / d['time'] / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
+            'traffic_source': src, 'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
+            'algorithmic_flops_per_launch': d['flops'] / d['launches'],
             'kernel': 'gemm_nt_kernel<%s,%s,%d,%d,2>' % ('bf16' if dtype == torch.bfloat16 else 'f32', 'f32' if dom[2] == 0 else 'bf16', dom[0], dom[1]),
             'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),

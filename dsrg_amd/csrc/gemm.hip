@@ -23,6 +23,7 @@ struct GemmArgs {
   int tile_start[DSRG_MAX_GROUPS + 1];
   int nprob;
   int act;
+  int gm;          // M-tiles per super-row of the tile walk
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   const int M = P.M, N = P.N, K = P.K;
   const int t = bid - args.tile_start[g];
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  constexpr int GM = 4;
+  const int GM = args.gm;
   const int per_group = GM * tiles_n;
   const int grp = t / per_group, in_grp = t - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);          // rows in this (possibly short) super-row
@@ -273,6 +274,9 @@ template <typename T, typename OutT>
 int dispatch_tile(GemmArgs& a, hipStream_t s) {
   int bm, bn;
   const int tiles = plan_tiles(a, bm, bn);
+  static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
+  a.gm = gm_env ? atoi(gm_env) : 4;
+  if (a.gm < 1) a.gm = 1;
   const int nst = g_nst_override;       // tuning aid only; the shipped ring depth is 2
   if (bm == 128) {
     if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
