@@ -7,7 +7,10 @@ One step = one 'panorama' + one 'navigation' call on a batch of 64 episodes (syn
 inside the timed region, as a rollout would.  N>1: one process per GPU (torchrun), independent replicas of 64
 episodes each (weak scaling, no data-path collective); value = N*64*K / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--dtype bf16|fp32] [--eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1|c4] [--dtype bf16|fp32] [--eager]
+
+--config c4 is BASELINE config[3]: one R2R pre-training optimisation step (MLM / MRC / SAP round-robin, forward +
+backward + gradient clipping + AdamW, 24 trajectories per GPU, DDP gradient all-reduce over RCCL when N>1).
 """
 import argparse
 import json
@@ -132,14 +135,13 @@ def pmc_traffic(kernel_sig, grids):
     return tot / len(grids), os.path.basename(fetch[-1])
 
 
-def gemm_roofline(model, runner, dtype):
+def gemm_roofline(step_fn, dtype):
     """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step, then re-issue
     each launch `rep` times back to back between HIP events on the launch stream; achieved = algorithmic FLOPs of the
     launches of the dominant tile variant / their measured time."""
     from dsrg_amd import kernels
     kernels.GEMM_TRACE = []
-    with torch.no_grad():
-        runner._body()
+    step_fn()
     trace, kernels.GEMM_TRACE = kernels.GEMM_TRACE, None
     torch.cuda.synchronize()
     rep = 20
@@ -174,12 +176,112 @@ def gemm_roofline(model, runner, dtype):
             'all_gemm_us_per_step': tot_t * 1e6}
 
 
+PT_TASKS = ('mlm', 'mrc', 'sap')      # mix of PT/config/r2r_pretrain.json, one task per optimisation step
+PT_B, PT_L = 24, 80                   # trajectories per GPU, instruction length
+
+
+def pretrain_main(a, dtype, dev, rank, world):
+    """BASELINE config[3]: pre-training step = forward + backward (+ DDP all-reduce) + clip_grad_norm_(5.0) + AdamW, as
+    PT/train_r2r.py:239-295.  Dropout is on (p=0.1, the reference's model config).  Weak scaling: 24 trajectories per GPU."""
+    from dsrg_amd import synth, distributed as D
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain import GlocalTextPathCMTPreTraining
+    cfg = DSRGConfig(use_lang2visn_attn=True, obj_feat_size=0, pretrain_tasks=PT_TASKS)
+    model = GlocalTextPathCMTPreTraining(cfg, compute_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes).items()}
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    ddp = D.wrap_model(model, dev, bf16_grads=(dtype == torch.bfloat16))
+    decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in ('bias', 'LayerNorm'))]
+    nodecay = [p for n, p in model.named_parameters() if p.requires_grad and any(t in n for t in ('bias', 'LayerNorm'))]
+    opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': nodecay, 'weight_decay': 0.0}],
+                            lr=5e-5, betas=(0.9, 0.98), fused=True)
+    batches = {t: T(synth.pretrain_batch(PT_B, PT_L, 3, 200 + rank, t, min_steps=4, max_steps=7), dev) for t in PT_TASKS}
+    last = {}
+
+    def step(i):
+        task = PT_TASKS[i % len(PT_TASKS)]
+        if world > 1:
+            task = PT_TASKS[D.broadcast_task_id(PT_TASKS.index(task), dev)]
+        opt.zero_grad(set_to_none=True)
+        loss = ddp(batches[task], task, compute_loss=True).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        last[task] = loss.detach()
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert all(torch.isfinite(v) for v in last.values()), 'non-finite pre-training loss'
+    if rank == 0:
+        nsteps = {t: int(batches[t]['traj_view_img_fts'].shape[0]) for t in PT_TASKS}
+        out = {'metric': 'R2R pre-training optimisation steps (MLM+MRC+SAP round-robin): trajectories/s', 'value': world * PT_B * a.steps / dt,
+               'unit': 'trajectories/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+               'config': {'workload': 'BASELINE config[3]: R2R pre-training step, forward+backward+clip+AdamW, %s' % a.dtype, 'name': 'c4',
+                          'trajectories_per_gpu': PT_B, 'txt_len': PT_L, 'trajectory_steps_total': nsteps, 'dropout': cfg.hidden_dropout_prob,
+                          'parallelism': 'DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if world > 1 else 'single GPU'},
+               'final_losses': {t: float(v) for t, v in last.items()}}
+        if not a.no_roofline:
+            # DDP hooks must not fire during the replayed step: run it on the bare module
+            def one_step():
+                opt.zero_grad(set_to_none=True)
+                model(batches['sap'], 'sap', compute_loss=True).mean().backward()
+            out['roofline'] = gemm_roofline(one_step, dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = pretrain_cpu_baseline(cfg, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pretrain_cpu_baseline(cfg, sd, budget_s=25.0):
+    """CPU oracle (oracle/pretrain_oracle.py) forward+backward on a bounded sample: 4 trajectories per step."""
+    from dsrg_amd import synth
+    from oracle import pretrain_oracle
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = {k: v.clone().float().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    Bc = 4
+    bs = {t: T(synth.pretrain_batch(Bc, PT_L, 3, 200, t, min_steps=4, max_steps=7), 'cpu') for t in PT_TASKS}
+    import copy
+    c0 = copy.copy(cfg); c0.hidden_dropout_prob = 0.0; c0.attention_probs_dropout_prob = 0.0
+    t0, it = time.perf_counter(), 0
+    while it < len(PT_TASKS) or (time.perf_counter() - t0 < budget_s and it < 12):
+        task = PT_TASKS[it % len(PT_TASKS)]
+        pretrain_oracle.forward(sd, c0, bs[task], task, True).mean().backward()
+        for v in sd.values():
+            v.grad = None
+        it += 1
+    dt = time.perf_counter() - t0
+    return {'value': Bc * it / dt, 'unit': 'trajectories/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d forward+backward steps of %d trajectories (no optimiser step, fp32, %d threads), %.1f s' % (it, Bc, cores, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--warmup', type=int, default=15)
-    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c4'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--eager', action='store_true', help='launch kernels from Python each step instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -196,6 +298,8 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
 
+    if a.config == 'c4':
+        return pretrain_main(a, dtype, dev, rank, world)
     from dsrg_amd.runner import GraphedNavStep
     model, cfg, sd, lbs, pb, nb, dims = build(a.config, dtype, dev)
     reverie, B, L, G, O, No, Vp = dims
@@ -249,7 +353,10 @@ def main():
             'whole_step_frac_of_mfma_peak': B * a.steps * fl / dt / (MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32),
         }
         if not a.no_roofline:
-            out['roofline'] = gemm_roofline(model, runner, dtype)
+            def one_step():
+                with torch.no_grad():
+                    runner._body()
+            out['roofline'] = gemm_roofline(one_step, dtype)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, sd, lbs[0], pb, nb, dims)
         print(json.dumps(out), flush=True)
