@@ -64,6 +64,104 @@ def _call(hip_fn, aten_fn, *args):
     return hip_fn(*args)
 
 
+# ----------------------------------------------------------------------------- weight packing
+def _foreach_copy_grouped(dsts, srcs):
+    """torch._foreach_copy_ per (destination dtype, source dtype) group: its multi-tensor fast path needs one dtype
+    per list."""
+    groups = {}
+    for d, s_ in zip(dsts, srcs):
+        g = groups.setdefault((d.dtype, s_.dtype), ([], []))
+        g[0].append(d); g[1].append(s_)
+    for d, s_ in groups.values():
+        torch._foreach_copy_(d, s_)
+
+
+class _PackFn(torch.autograd.Function):
+    """All compute-dtype / packed copies of the parameters in one autograd node: forward = one multi-tensor copy
+    (torch._foreach_copy_, casts included) of every source into its row range of its packed buffer; backward = one
+    multi-tensor copy of the packed gradients' row ranges back into fresh parameter-dtype gradients.  Replaces one
+    cast (+ one cat) kernel per weight and their autograd mirrors (~1000 tiny launches per training step)."""
+
+    @staticmethod
+    def forward(ctx, spec, *srcs):
+        outs, dst = [], []
+        for dtype, idxs in spec:
+            rows = sum(srcs[i].shape[0] for i in idxs)
+            o = torch.empty((rows,) + tuple(srcs[idxs[0]].shape[1:]), device=srcs[idxs[0]].device, dtype=dtype)
+            r = 0
+            for i in idxs:
+                dst.append((i, o[r:r + srcs[i].shape[0]]))
+                r += srcs[i].shape[0]
+            outs.append(o)
+        _foreach_copy_grouped([d for _, d in dst], [srcs[i].detach() for i, _ in dst])
+        if isinstance(ctx, torch.autograd.function.FunctionCtx):
+            ctx.set_materialize_grads(False)       # weights a task does not touch get no gradient, not a zero tensor
+        ctx.spec = spec
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in srcs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        grads = [None] * len(ctx.meta)
+        dst, src = [], []
+        for (dtype, idxs), g in zip(ctx.spec, gouts):
+            if g is None:
+                continue
+            r = 0
+            for i in idxs:
+                shape, dt, dev = ctx.meta[i]
+                if ctx.needs_input_grad[1 + i]:
+                    grads[i] = torch.empty(shape, dtype=dt, device=dev)
+                    dst.append(grads[i]); src.append(g[r:r + shape[0]])
+                r += shape[0]
+        if dst:
+            _foreach_copy_grouped(dst, src)
+        return (None,) + tuple(grads)
+
+
+class WeightPacker:
+    """Collects cast / concat requests while a weight dict is being built and serves them with one _PackFn call.
+    `cast(t)` / `cat(ts)` return placeholders; `resolve(W)` swaps them for the packed tensors."""
+
+    class _Lazy:
+        __slots__ = ('k',)
+
+        def __init__(self, k):
+            self.k = k
+
+    def __init__(self):
+        self.srcs, self.spec = [], []
+
+    def cat(self, ts, dtype):
+        idxs = []
+        for t in ts:
+            idxs.append(len(self.srcs)); self.srcs.append(t)
+        self.spec.append((dtype, tuple(idxs)))
+        return WeightPacker._Lazy(len(self.spec) - 1)
+
+    def cast(self, t, dtype):
+        if t.dtype == dtype and t.is_contiguous():
+            return t
+        return self.cat([t], dtype)
+
+    def resolve(self, W):
+        if not self.spec:
+            return W
+        if _needs_grad(self.srcs):
+            outs = _PackFn.apply(tuple(self.spec), *self.srcs)
+        else:
+            with torch.no_grad():
+                outs = _PackFn.forward(_NoCtx(), tuple(self.spec), *self.srcs)
+        for k, v in W.items():
+            if isinstance(v, WeightPacker._Lazy):
+                W[k] = outs[v.k]
+        return W
+
+
+class _NoCtx:
+    pass
+
+
 # ----------------------------------------------------------------------------- linear (grouped), hand-written backward
 def _as2d(t):
     """[..., H] view with uniformly strided rows -> 2-D [M, H] view (no copy)."""
@@ -337,9 +435,9 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
         if base is not None:
             z = z + base.reshape(M, H).float()
         if E1 is not None:
-            z = z + E1[_rows_index(idx1, M)]
+            z = z + F.embedding(_rows_index(idx1, M), E1)      # embedding_dense_backward, not the slow index_put path
         if E2 is not None:
-            z = z + E2[_rows_index(idx2, M)]
+            z = z + F.embedding(_rows_index(idx2, M), E2)
         if vec is not None:
             z = z + vec
         if lno_g is not None:

@@ -338,7 +338,8 @@ def layernorm_bwd(x, residual, gamma, dy, eps):
     H = x.shape[-1]
     dy = dy if dy.stride(-1) == 1 else dy.contiguous()
     dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
-    dg, db = torch.zeros(H, device=x.device, dtype=torch.float32), torch.zeros(H, device=x.device, dtype=torch.float32)
+    dgb = torch.zeros(2, H, device=x.device, dtype=torch.float32)
+    dg, db = dgb[0], dgb[1]
     ldr = _rows(residual)[1] if residual is not None else 0
     _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
                                       _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')

@@ -192,8 +192,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         """compute-dtype views of the head weights (differentiable; small)."""
         cd = self.bert.compute_dtype
         W = {}
-        c = lambda t: t.to(cd).contiguous()
-        f = lambda t: t.float().contiguous()
+        pk = Fn.WeightPacker()
+        c = lambda t: pk.cast(t, cd)
+        f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else pk.cast(t, torch.float32)
         lin = lambda k, m: W.update({k + '.w': c(m.weight), k + '.b': f(m.bias) if m.bias is not None else None})
         ln = lambda k, m: W.update({k + '.g': f(m.weight), k + '.b': f(m.bias)})
         for k in ('global_sap_head', 'local_sap_head', 'sap_fuse_linear', 'og_head', 'image_classifier', 'obj_classifier'):
@@ -204,7 +205,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             p = self.mlm_head.predictions
             lin('mlm.t', p.transform.dense); ln('mlm.ln', p.transform.LayerNorm)
             W['mlm.dec.w'], W['mlm.dec.b'] = c(p.decoder.weight), f(p.bias)
-        return W
+        return pk.resolve(W)
 
     def _scores(self, W, key, x):
         """ClsPrediction -> [..] raw scores (Linear+ReLU in the GEMM epilogue, LN+Linear(H,1) tail kernel)."""

@@ -238,8 +238,9 @@ class GlocalTextPathNavCMT(nn.Module):
         if not grad and self._wcache is not None:
             return self._wcache
         cd = self.compute_dtype
-        c = lambda t: t.to(cd).contiguous()
-        f = lambda t: t.float().contiguous()
+        pk = Fn.WeightPacker()          # every cast / concat below is served by ONE multi-tensor copy (and one in backward)
+        c = lambda t: pk.cast(t, cd)
+        f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else pk.cast(t.contiguous() if t.dim() == 1 else t, torch.float32)
         W = {}
 
         def lin(key, m):
@@ -249,8 +250,8 @@ class GlocalTextPathNavCMT(nn.Module):
             W[key + '.g'], W[key + '.b'] = f(m.weight), f(m.bias)
 
         def packed(key, mods):
-            W[key + '.w'] = c(torch.cat([m.weight for m in mods], 0))
-            W[key + '.b'] = f(torch.cat([m.bias for m in mods], 0))
+            W[key + '.w'] = pk.cat([m.weight for m in mods], cd)
+            W[key + '.b'] = pk.cat([m.bias for m in mods], torch.float32)
 
         def bert_layer(key, L):
             packed(key + '.qkv', [L.attention.self.query, L.attention.self.key, L.attention.self.value])
@@ -315,6 +316,7 @@ class GlocalTextPathNavCMT(nn.Module):
                     lin(k + '.lff1', L.lang_inter.dense); lin(k + '.lff2', L.lang_output.dense); ln(k + '.lfln', L.lang_output.LayerNorm)
         packed('x.txtkv', kv)       # [2 branches * layers * (K,V) * 768, 768]
         self._head_weights(W, lin, ln, f)
+        pk.resolve(W)
         if not grad:
             self._wcache = W
         return W
