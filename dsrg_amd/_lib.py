@@ -43,7 +43,7 @@ SIGNATURES = {
     'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    'dsrg_transpose_pad': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'dsrg_transpose_pad': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'dsrg_colsum_acc': (C.c_int, [_P, _I, _P, _I, _I, _I, _P]),
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),
     'dsrg_act_bwd': (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),

@@ -10,7 +10,7 @@ namespace {
 // out[c][r] = in[r][c]; out rows are zero-filled up to Rp >= R.  64x64 tiles through LDS (+1 pad: conflict-free).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const TI* __restrict__ in, int ld_in, TO* __restrict__ out, int ld_out,
-                                                            int R, int C, int Rp) {
+                                                            int R, int C, int Rp, float* __restrict__ colsum) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -24,6 +24,15 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const TI* __restrict
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + 4 * i, r = r0 + tx;
     if (c < C && r < Rp) Elem<TO>::st(out + (size_t)c * ld_out + r, tile[tx][ty + 4 * i]);
+  }
+  if (colsum) {        // the bias gradient rides along: column sums of this 64-row strip, one atomic per column
+    __shared__ float part[4][64];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += tile[ty + 4 * i][tx];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < C) atomicAdd(colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
   }
 }
 
@@ -161,16 +170,16 @@ inline bool okdt(int d) { return d == DSRG_F32 || d == DSRG_BF16; }
 }  // namespace
 
 extern "C" int dsrg_transpose_pad(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rp, int in_dtype, int out_dtype,
-                                  void* stream) {
+                                  float* colsum, void* stream) {
   DSRG_CHECK(in && out && okdt(in_dtype) && okdt(out_dtype), "dsrg_transpose_pad: bad pointer or dtype");
   DSRG_CHECK(R >= 0 && C >= 0 && Rp >= R && ld_in >= C && ld_out >= Rp, "dsrg_transpose_pad: bad dims R=%d C=%d Rp=%d ld_in=%d ld_out=%d", R, C, Rp, ld_in, ld_out);
   if (C == 0 || Rp == 0) return DSRG_OK;
   dim3 grid((C + 63) / 64, (Rp + 63) / 64), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == DSRG_F32 && out_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<float, float>), grid, block, 0, s, (const float*)in, ld_in, (float*)out, ld_out, R, C, Rp);
-  else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<float, bf16_t>), grid, block, 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, R, C, Rp);
-  else if (out_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)in, ld_in, (float*)out, ld_out, R, C, Rp);
-  else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C, Rp);
+  if (in_dtype == DSRG_F32 && out_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<float, float>), grid, block, 0, s, (const float*)in, ld_in, (float*)out, ld_out, R, C, Rp, colsum);
+  else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<float, bf16_t>), grid, block, 0, s, (const float*)in, ld_in, (bf16_t*)out, ld_out, R, C, Rp, colsum);
+  else if (out_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)in, ld_in, (float*)out, ld_out, R, C, Rp, colsum);
+  else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C, Rp, colsum);
   DSRG_LAUNCH_CHECK("dsrg_transpose_pad");
   return DSRG_OK;
 }

@@ -172,24 +172,33 @@ def _as2d(t):
 
 
 def _gemm_grads(items):
-    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw) -> (dx list, dw list); every group of
-    dgrad / wgrad GEMMs is ONE grouped launch of the forward NT kernel on transposed operands."""
-    dxp, dwp = [], []
-    for x, w, dy, ndx, ndw in items:
+    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw, need_db) -> (dx list, dw list, db list); every
+    group of dgrad / wgrad GEMMs is ONE grouped launch of the forward NT kernel on transposed operands; the bias
+    gradients (column sums of dy) are taken by the kernel that transposes dy, into one zeroed buffer."""
+    nb = sum(it[1].shape[0] for it in items if it[5])
+    dball = torch.zeros(nb, device=items[0][2].device, dtype=torch.float32) if nb else None
+    dxp, dwp, dbs, o = [], [], [], 0
+    for x, w, dy, ndx, ndw, ndb in items:
         N, Kd = w.shape
+        db = None
+        if ndb:
+            db = dball[o:o + N]; o += N
         if ndx:
             Np = (N + 63) // 64 * 64
             dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
             dxp.append((dyp, K.transpose_pad(w), None, None))            # [M,Np] x [K,Np]^T
         if ndw:
-            dwp.append((K.transpose_pad(dy), K.transpose_pad(x), None, None))   # [N,Mp] x [K,Mp]^T
+            dwp.append((K.transpose_pad(dy, colsum=db), K.transpose_pad(x), None, None))   # [N,Mp] x [K,Mp]^T
+        elif ndb:
+            db.copy_(K.colsum(dy))
+        dbs.append(db)
     dxs = K.gemm(dxp) if dxp else []
     dws = K.gemm(dwp) if dwp else []
     outx, outw = [], []
-    for x, w, dy, ndx, ndw in items:
+    for x, w, dy, ndx, ndw, ndb in items:
         outx.append(dxs.pop(0) if ndx else None)
         outw.append(dws.pop(0) if ndw else None)
-    return outx, outw
+    return outx, outw, dbs
 
 
 class _LinearFn(torch.autograd.Function):
@@ -220,16 +229,15 @@ class _LinearFn(torch.autograd.Function):
             dy2 = _as2d(dy if dy.stride(-1) == 1 else dy.contiguous())
             if dy2.dtype != w.dtype:
                 dy2 = dy2.to(w.dtype)
-            items.append((_as2d(x), w, dy2, ctx.needs_input_grad[2 + 4 * i], ctx.needs_input_grad[3 + 4 * i]))
+            items.append((_as2d(x), w, dy2, ctx.needs_input_grad[2 + 4 * i], ctx.needs_input_grad[3 + 4 * i],
+                          ctx.hasb[i] and ctx.needs_input_grad[4 + 4 * i]))
         live = [it for it in items if it is not None]
-        dxs, dws = _gemm_grads(live) if live else ([], [])
+        dxs, dws, dbs = _gemm_grads(live) if live else ([], [], [])
         for i in range(ctx.n):
             if items[i] is None:
                 res += [None, None, None, None]
                 continue
-            dx, dw = dxs.pop(0), dws.pop(0)
-            dy2 = items[i][2]
-            db = K.colsum(dy2) if (ctx.hasb[i] and ctx.needs_input_grad[4 + 4 * i]) else None
+            dx, dw, db = dxs.pop(0), dws.pop(0), dbs.pop(0)
             dr = None
             if ctx.rdt[i] is not None and ctx.needs_input_grad[5 + 4 * i]:
                 dr = dys[i].to(ctx.rdt[i])
@@ -297,16 +305,16 @@ class _LinearLNFn(torch.autograd.Function):
             if p_drop > 0:
                 zs = K.gemm([(p[0], p[1], p[2], None) for p in probs], ACT_NONE, True)
                 masks = []
-                for z in zs:
-                    m = (torch.rand_like(z) >= p_drop).to(z.dtype).mul_(1.0 / (1.0 - p_drop))
-                    z.mul_(m)
-                    masks.append(m.to(probs[0][1].dtype))
+                for i, z in enumerate(zs):
+                    zs[i], m = torch.native_dropout(z, p_drop, True)      # one kernel: dropped+scaled z and the bool mask
+                    masks.append(m)
                 ys = K.layernorm_grouped([(z, p[4], p[5], p[3]) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
             else:
                 masks = [None] * n
                 zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in probs], ACT_NONE, True)
                 ys = K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
         ctx.drop = p_drop > 0
+        ctx.scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         ctx.hasr = [p[3] is not None for p in probs]
         ctx.hasb = [p[2] is not None for p in probs]
         saved = []
@@ -329,19 +337,19 @@ class _LinearLNFn(torch.autograd.Function):
                 continue
             dy = dy if dy.dtype == w.dtype else dy.to(w.dtype)
             dz, dg, dbt = K.layernorm_bwd(z, r, gamma, dy, ctx.eps)
-            dlin = dz if m is None else dz * m
+            dlin = dz if m is None else torch.ops.aten.native_dropout_backward(dz, m, ctx.scale)
             keep.append((dz, dg, dbt, dlin))
-            items.append((_as2d(x), w, _as2d(dlin), ctx.needs_input_grad[3 + 6 * i], ctx.needs_input_grad[4 + 6 * i]))
+            items.append((_as2d(x), w, _as2d(dlin), ctx.needs_input_grad[3 + 6 * i], ctx.needs_input_grad[4 + 6 * i],
+                          ctx.hasb[i] and ctx.needs_input_grad[5 + 6 * i]))
         live = [it for it in items if it is not None]
-        dxs, dws = _gemm_grads(live) if live else ([], [])
+        dxs, dws, dbs = _gemm_grads(live) if live else ([], [], [])
         res = [None, None, None]
         for i in range(ctx.n):
             if items[i] is None:
                 res += [None] * 6
                 continue
             dz, dg, dbt, dlin = keep[i]
-            dx, dw = dxs.pop(0), dws.pop(0)
-            db = K.colsum(_as2d(dlin)) if (ctx.hasb[i] and ctx.needs_input_grad[5 + 6 * i]) else None
+            dx, dw, db = dxs.pop(0), dws.pop(0), dbs.pop(0)
             dr = dz if (ctx.hasr[i] and ctx.needs_input_grad[6 + 6 * i]) else None
             res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw, db, dr, dg, dbt]
         return tuple(res)

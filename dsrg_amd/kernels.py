@@ -292,14 +292,17 @@ def igl_blend(aug, x, wa, ba, wo, bo):
 
 
 # ----------------------------------------------------------------------------- backward-pass kernels
-def transpose_pad(x, out_dtype=None, pad_to=64):
-    """x [R,C] (row stride free) -> [C, Rp] with Rp = R rounded up to pad_to, zero filled."""
+def transpose_pad(x, out_dtype=None, pad_to=64, colsum=None):
+    """x [R,C] (row stride free) -> [C, Rp] with Rp = R rounded up to pad_to, zero filled.
+    colsum: optional zeroed fp32 [C]; receives the column sums of x (the bias gradient) in the same pass."""
     lib = _lib.load()
     _dev(x)
     R, C_ = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
     out = torch.empty(C_, Rp, device=x.device, dtype=out_dtype or x.dtype)
-    _lib.check(lib.dsrg_transpose_pad(_p(x), x.stride(0), _p(out), Rp, R, C_, Rp, _dt(x), _dt(out), _stream()), 'dsrg_transpose_pad')
+    if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != C_ or not colsum.is_contiguous()):
+        raise _lib.DsrgHipError('transpose_pad: colsum must be contiguous fp32 [C]')
+    _lib.check(lib.dsrg_transpose_pad(_p(x), x.stride(0), _p(out), Rp, R, C_, Rp, _dt(x), _dt(out), _p(colsum), _stream()), 'dsrg_transpose_pad')
     return out
 
 

@@ -159,9 +159,11 @@ int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const fl
  * GEMM gradients reuse dsrg_gemm_nt:  dX = gemm_nt(dY, Wt),  dW = gemm_nt(dYt, Xt)  with the transposes below. */
 
 /* out[c, r] = in[r, c] for r < R (zero for R <= r < Rp), c < C.  in is [R,C] (ld_in) of in_dtype, out is [C,Rp] (ld_out)
- * of out_dtype.  Rp is the row count padded to the GEMM's K granularity (64). */
+ * of out_dtype.  Rp is the row count padded to the GEMM's K granularity (64).
+ * colsum: NULL, or fp32 [C] accumulated with float atomics (zeroed by the caller): colsum[c] += sum_r in[r, c] - the
+ * bias gradient, taken while dY is being transposed for the weight gradient. */
 int dsrg_transpose_pad(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rp, int in_dtype,
-                       int out_dtype, void* stream);
+                       int out_dtype, float* colsum, void* stream);
 
 /* out[n] += sum_m in[m, n]  (bias gradient; out is fp32 and must be zeroed by the caller; float atomics). */
 int dsrg_colsum_acc(const void* in, int ld, float* out, int M, int N, int dtype, void* stream);

@@ -244,6 +244,9 @@ def test_transpose_colsum_act(K, dtype):
     assert t2.dtype == dtype and t2.shape == (768, 128)
     s = K.colsum(x)
     assert (s - x.float().sum(0)).abs().max().item() <= (1e-3 if dtype == torch.float32 else 2e-1)
+    cs = torch.zeros(130, device='cuda')           # column sums taken by the transposing kernel itself
+    t3 = K.transpose_pad(x, colsum=cs)
+    assert torch.equal(t3, t) and (cs - x.float().sum(0)).abs().max().item() <= 1e-3
     z = _r(64, 3072, dtype=dtype)
     dy = _r(64, 3072, seed=1, dtype=dtype)
     for act in (1, 2, 3):
@@ -307,3 +310,25 @@ def test_functional_grads_match_autograd(dtype):
         ref = t.grad.float()
         err = (m - ref).abs().max().item()
         assert err <= tol * max(1.0, ref.abs().max().item()), (tuple(t.shape), err, ref.abs().max().item())
+
+
+def test_dense_dropout_residual_ln_train_path():
+    """the p_drop > 0 branch of the dense+dropout+residual+LayerNorm composite (training only): with the weight set to
+    zero the dropped term vanishes, so output and input gradients must equal the plain LayerNorm(residual + bias) ones."""
+    from dsrg_amd import functional as Fn
+    torch.manual_seed(0)
+    M, H = 96, 768
+    x = _r(M, H, dtype=torch.bfloat16).requires_grad_(True)
+    r = _r(M, H, seed=1, dtype=torch.bfloat16).requires_grad_(True)
+    w = torch.zeros(H, H, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+    b = torch.zeros(H, device='cuda', requires_grad=True)
+    g, be = (1 + 0.1 * _r(H, seed=2)).requires_grad_(True), (0.1 * _r(H, seed=3)).requires_grad_(True)
+    y = Fn.linear_ln(x, w, b, g, be, 1e-12, residual=r, p_drop=0.3)
+    dy = _r(M, H, seed=4, dtype=torch.bfloat16)
+    y.backward(dy)
+    rr = r.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(rr, (H,), g.detach(), be.detach(), 1e-12)
+    ref.backward(dy.float())
+    assert (y.float() - ref).abs().max().item() <= 3e-2
+    assert (r.grad.float() - rr.grad).abs().max().item() <= 3e-2 * rr.grad.abs().max().item() + 1e-3
+    assert torch.isfinite(w.grad).all() and torch.isfinite(b.grad).all() and x.grad.abs().max().item() == 0.0
