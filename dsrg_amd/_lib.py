@@ -20,6 +20,16 @@ class GemmProblem(C.Structure):
                 ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32)]
 
 
+class AttnProblem(C.Structure):
+    _fields_ = [('Q', C.c_void_p), ('K', C.c_void_p), ('V', C.c_void_p), ('O', C.c_void_p),
+                ('q_bs', C.c_int64), ('k_bs', C.c_int64), ('v_bs', C.c_int64), ('o_bs', C.c_int64),
+                ('q_rs', C.c_int32), ('k_rs', C.c_int32), ('v_rs', C.c_int32), ('o_rs', C.c_int32),
+                ('kmask', C.c_void_p), ('pair_dists', C.c_void_p), ('lse', C.c_void_p), ('Nq', C.c_int32), ('Nk', C.c_int32)]
+
+
+ATTN_MAX_GROUPS = 4
+
+
 class LnProblem(C.Structure):
     _fields_ = [('x', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('out', C.c_void_p),
                 ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32)]
@@ -33,6 +43,7 @@ SIGNATURES = {
     'dsrg_gemm_nt_plan': (C.c_int, [C.POINTER(GemmProblem), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dsrg_attention_fwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _P, _P,
                                      _I, _I, _I, _I, _F, _P, _I, _P]),
+    'dsrg_attention_fwd_grouped': (C.c_int, [C.POINTER(AttnProblem), _I, _I, _P, _P, _I, _I, _F, _I, _P]),
     'dsrg_attention_bwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),

@@ -22,14 +22,29 @@ struct AttnArgs {
   int NH;
 };
 
+// up to DSRG_ATTN_MAX_GROUPS independent problems (same B, NH, mask mode, dtype) in one launch: blockIdx.x walks the
+// query blocks of problem 0, then problem 1, ...
+struct AttnGroup {
+  AttnArgs a[DSRG_ATTN_MAX_GROUPS];
+  int start[DSRG_ATTN_MAX_GROUPS + 1];
+  int n;
+};
+#define ATTN_PICK_PROBLEM(grp)                                   \
+  int gsel = 0;                                                  \
+  _Pragma("unroll") for (int i_ = 1; i_ < DSRG_ATTN_MAX_GROUPS; ++i_) \
+    if (i_ < grp.n && (int)blockIdx.x >= grp.start[i_]) gsel = i_;    \
+  const AttnArgs& a = grp.a[gsel];                               \
+  const int bx = (int)blockIdx.x - grp.start[gsel];
+
 template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
+  ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
   __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
   __shared__ __attribute__((aligned(16))) float Ps[4 * KT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QPB;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = bx * QPB;
   const T* Qp = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * DH;
   const T* Kp = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * DH;
   const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
@@ -131,14 +146,15 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnGroup grp) {
+  ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
   __shared__ float mt[KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const int q0 = (bx * 4 + wave) * 16;
   const bool active = q0 < a.Nq;                               // wave-uniform
   const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
@@ -512,39 +528,56 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 
 }  // namespace
 
+extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, int nproblems, int mask_mode,
+                                          const float* sprel_w, const float* sprel_b, int B, int NH, float scale, int dtype,
+                                          void* stream) {
+  DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_ATTN_MAX_GROUPS, "dsrg_attention_fwd: nproblems=%d out of [1,%d]", nproblems,
+             DSRG_ATTN_MAX_GROUPS);
+  DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_fwd: bad dtype %d", dtype);
+  DSRG_CHECK(B >= 0 && NH >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_fwd: bad dims B=%d NH=%d", B, NH);
+  DSRG_CHECK(mask_mode >= DSRG_MASK_NONE && mask_mode <= DSRG_MASK_PLUS1, "dsrg_attention_fwd: bad mask_mode %d", mask_mode);
+  const uintptr_t am = dtype == DSRG_BF16 ? 7 : 15;
+  AttnGroup grp;
+  grp.n = 0;
+  bool mfma_ok = dtype == DSRG_BF16;
+  for (int i = 0; i < nproblems; ++i) {
+    const dsrg_attn_problem_t& p = problems[i];
+    DSRG_CHECK(p.Nq >= 0 && p.Nk >= 1, "dsrg_attention_fwd: problem %d has bad dims Nq=%d Nk=%d", i, p.Nq, p.Nk);
+    if (p.Nq == 0) continue;
+    DSRG_CHECK(p.Q && p.K && p.V && p.O, "dsrg_attention_fwd: problem %d has a null Q/K/V/O", i);
+    DSRG_CHECK(mask_mode == DSRG_MASK_NONE || p.kmask, "dsrg_attention_fwd: mask_mode %d needs kmask (problem %d)", mask_mode, i);
+    DSRG_CHECK(!p.pair_dists || (sprel_w && sprel_b), "dsrg_attention_fwd: pair_dists needs sprel_w and sprel_b");
+    DSRG_CHECK(p.q_rs % 4 == 0 && p.k_rs % 4 == 0 && p.v_rs % 4 == 0 && p.q_bs % 4 == 0 && p.k_bs % 4 == 0 && p.v_bs % 4 == 0,
+               "dsrg_attention_fwd: problem %d strides must be multiples of 4 elements", i);
+    DSRG_CHECK(p.q_rs >= NH * 64 && p.k_rs >= NH * 64 && p.v_rs >= NH * 64 && p.o_rs >= NH * 64,
+               "dsrg_attention_fwd: problem %d row strides smaller than NH*64", i);
+    DSRG_CHECK(((uintptr_t)p.Q & am) == 0 && ((uintptr_t)p.K & am) == 0 && ((uintptr_t)p.V & am) == 0, "dsrg_attention_fwd: problem %d misaligned Q/K/V", i);
+    mfma_ok = mfma_ok && p.q_rs % 8 == 0 && p.k_rs % 8 == 0 && p.v_rs % 8 == 0 && p.q_bs % 8 == 0 && p.k_bs % 8 == 0 && p.v_bs % 8 == 0 &&
+              p.o_rs % 4 == 0 && p.o_bs % 4 == 0 && (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.O & 7) == 0;
+    grp.a[grp.n++] = AttnArgs{p.Q, p.K, p.V, p.O, p.q_bs, p.k_bs, p.v_bs, p.o_bs, p.q_rs, p.k_rs, p.v_rs, p.o_rs,
+                              mask_mode == DSRG_MASK_NONE ? nullptr : p.kmask, mask_mode, p.pair_dists, sprel_w, sprel_b, p.Nq, p.Nk, scale,
+                              p.lse, NH};
+  }
+  if (B == 0 || grp.n == 0) return DSRG_OK;
+  const int qpb = mfma_ok ? 64 : QPB;           // query rows per workgroup
+  int blocks = 0;
+  for (int i = 0; i < grp.n; ++i) { grp.start[i] = blocks; blocks += (grp.a[i].Nq + qpb - 1) / qpb; }
+  grp.start[grp.n] = blocks;
+  dim3 grid(blocks, NH, B), block(256);
+  if (mfma_ok) hipLaunchKernelGGL(attention_mfma_kernel, grid, block, 0, (hipStream_t)stream, grp);
+  else if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, grp);
+  else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, grp);
+  DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
+  return DSRG_OK;
+}
+
 extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
                                   const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
                                   const uint8_t* kmask, int mask_mode, const float* pair_dists,
                                   const float* sprel_w, const float* sprel_b,
                                   int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream) {
-  DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_fwd: bad dtype %d", dtype);
-  DSRG_CHECK(Q && K && V && O, "dsrg_attention_fwd: null Q/K/V/O");
-  DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0 && Nk >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_fwd: bad dims B=%d NH=%d Nq=%d Nk=%d", B, NH, Nq, Nk);
-  DSRG_CHECK(mask_mode >= DSRG_MASK_NONE && mask_mode <= DSRG_MASK_PLUS1, "dsrg_attention_fwd: bad mask_mode %d", mask_mode);
-  DSRG_CHECK(mask_mode == DSRG_MASK_NONE || kmask, "dsrg_attention_fwd: mask_mode %d needs kmask", mask_mode);
-  DSRG_CHECK(!pair_dists || (sprel_w && sprel_b), "dsrg_attention_fwd: pair_dists needs sprel_w and sprel_b");
-  const int al = dtype == DSRG_BF16 ? 4 : 4;
-  DSRG_CHECK(q_rs % al == 0 && k_rs % al == 0 && v_rs % al == 0 && q_bs % al == 0 && k_bs % al == 0 && v_bs % al == 0,
-             "dsrg_attention_fwd: strides must be multiples of %d elements", al);
-  DSRG_CHECK(q_rs >= NH * 64 && k_rs >= NH * 64 && v_rs >= NH * 64 && o_rs >= NH * 64, "dsrg_attention_fwd: row strides smaller than NH*64");
-  const uintptr_t am = dtype == DSRG_BF16 ? 7 : 15;
-  DSRG_CHECK(((uintptr_t)Q & am) == 0 && ((uintptr_t)K & am) == 0 && ((uintptr_t)V & am) == 0, "dsrg_attention_fwd: misaligned Q/K/V");
-  if (B == 0 || Nq == 0) return DSRG_OK;
-  AttnArgs a{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask, mask_mode,
-             pair_dists, sprel_w, sprel_b, Nq, Nk, scale, lse, NH};
-  dim3 grid((Nq + QPB - 1) / QPB, NH, B), block(256);
-  const bool mfma_ok = dtype == DSRG_BF16 && q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
-                       v_bs % 8 == 0 && o_rs % 4 == 0 && o_bs % 4 == 0 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 &&
-                       ((uintptr_t)O & 7) == 0;
-  if (mfma_ok) {
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3((Nq + 63) / 64, NH, B), block, 0, (hipStream_t)stream, a);
-    DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
-    return DSRG_OK;
-  }
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a);
-  DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
-  return DSRG_OK;
+  const dsrg_attn_problem_t p{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, kmask, pair_dists, lse, Nq, Nk};
+  return dsrg_attention_fwd_grouped(&p, 1, mask_mode, sprel_w, sprel_b, B, NH, scale, dtype, stream);
 }
 
 extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,

@@ -394,6 +394,16 @@ def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=
     return K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sprel_w, sprel_b, scale)
 
 
+def attention_grouped(problems, nh, mask_mode=MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125):
+    """problems: list of (q, k, v, kmask, dists|None): one launch when no gradient is needed (the two branches of an
+    x-layer), one differentiable call per problem otherwise."""
+    flat = [t for p in problems for t in p[:3]] + [sprel_w, sprel_b]
+    if _needs_grad(flat) or len(problems) > _lib.ATTN_MAX_GROUPS:
+        return [attention(q, k, v, nh, km, mask_mode, d, sprel_w if d is not None else None, sprel_b if d is not None else None, scale)
+                for q, k, v, km, d in problems]
+    return K.attention_grouped(problems, nh, mask_mode, sprel_w, sprel_b, scale)
+
+
 # ----------------------------------------------------------------------------- layernorm
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod

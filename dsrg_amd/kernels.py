@@ -130,6 +130,41 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     return (out, lse) if want_lse else out
 
 
+def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125):
+    """problems: list (<= 4) of (q, k, v, kmask|None, dists|None) sharing B, nh, mask mode and dtype -> outputs, ONE launch."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= _lib.ATTN_MAX_GROUPS:
+        raise _lib.DsrgHipError('attention_grouped: %d problems (max %d)' % (n, _lib.ATTN_MAX_GROUPS))
+    q0 = problems[0][0]
+    _dev(q0)
+    B = q0.shape[0]
+    arr = (_lib.AttnProblem * n)()
+    outs = []
+    for i, (q, k, v, kmask, dists) in enumerate(problems):
+        Nq, Nk = q.shape[1], k.shape[1]
+        for t in (q, k, v):
+            if t.stride(2) != 1 or t.dtype != q0.dtype or t.shape[0] != B:
+                raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes and batch equal')
+        if kmask is not None and (kmask.dtype != torch.bool or kmask.shape != (B, Nk) or not kmask.is_contiguous()):
+            raise _lib.DsrgHipError('attention: kmask must be contiguous bool [B,Nk]')
+        if (kmask is None) != (mask_mode == _lib.MASK_NONE):
+            raise _lib.DsrgHipError('attention_grouped: kmask and mask_mode disagree')
+        if dists is not None and (dists.dtype != torch.float32 or dists.shape != (B, Nq, Nk) or not dists.is_contiguous()):
+            raise _lib.DsrgHipError('attention: pair_dists must be contiguous fp32 [B,Nq,Nk]')
+        out = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
+        outs.append(out)
+        bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
+        a = arr[i]
+        a.Q, a.K, a.V, a.O = _p(q), _p(k), _p(v), _p(out)
+        a.q_bs, a.k_bs, a.v_bs, a.o_bs = bs(q), bs(k), bs(v), out.stride(0)
+        a.q_rs, a.k_rs, a.v_rs, a.o_rs = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+        a.kmask, a.pair_dists, a.lse, a.Nq, a.Nk = _p(kmask), _p(dists), None, Nq, Nk
+    _lib.check(lib.dsrg_attention_fwd_grouped(arr, n, mask_mode, _p(sprel_w), _p(sprel_b), B, nh, float(scale), _dt(q0), _stream()),
+               'dsrg_attention_fwd_grouped')
+    return outs
+
+
 def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125):
     """-> dq, dk, dv (contiguous), dsprel fp32 [2] (or None)"""
     lib = _lib.load()

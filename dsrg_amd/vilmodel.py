@@ -514,17 +514,13 @@ class GlocalTextPathNavCMT(nn.Module):
         for i in range(nl):
             ks = ['x.%s.%d' % (b, i) for b in brs]
             q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(n)])
-            a = []
-            for j in range(n):
-                off = ((('g', 'l').index(brs[j]) * nl + i) * 2) * H
-                a.append(Fn.attention(q[j], kv[..., off:off + H], kv[..., off + H:off + 2 * H], nh, txt_masks, MASK_NEG10000))
+            offs = [((('g', 'l').index(brs[j]) * nl + i) * 2) * H for j in range(n)]
+            a = Fn.attention_grouped([(q[j], kv[..., o:o + H], kv[..., o + H:o + 2 * H], txt_masks, None) for j, o in enumerate(offs)],
+                                     nh, MASK_NEG10000)
             feats = self._grouped_res_ln(W, ks, '.co', '.cln', a, feats, eps)
             qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(n)])
-            a = []
-            for j in range(n):
-                sp = brs[j] == 'g' and dists is not None
-                a.append(Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, masks[j], MASK_NEG10000,
-                                      dists if sp else None, sw if sp else None, sb if sp else None))
+            a = Fn.attention_grouped([(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], masks[j],
+                                       dists if brs[j] == 'g' else None) for j in range(n)], nh, MASK_NEG10000, sw, sb)
             feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
             inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(n)], act=ACT_GELU)
             feats = self._grouped_res_ln(W, ks, '.ff2', '.fln', inter, feats, eps)

@@ -73,6 +73,23 @@ int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int
                        const float* sprel_w, const float* sprel_b,
                        int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream);
 
+/* The same for up to DSRG_ATTN_MAX_GROUPS independent problems that share B, NH, mask mode, scale and dtype, in ONE
+ * launch: the global and the local branch of an x-layer attend at the same point (FT/vilmodel.py:540-549). */
+#define DSRG_ATTN_MAX_GROUPS 4
+typedef struct {
+  const void *Q, *K, *V;
+  void* O;
+  int64_t q_bs, k_bs, v_bs, o_bs;   /* batch strides (elements) */
+  int32_t q_rs, k_rs, v_rs, o_rs;   /* row strides (elements) */
+  const uint8_t* kmask;             /* [B,Nk] or NULL (mask_mode NONE) */
+  const float* pair_dists;          /* [B,Nq,Nk] or NULL */
+  float* lse;                       /* [B,NH,Nq] or NULL */
+  int32_t Nq, Nk;
+} dsrg_attn_problem_t;
+int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems /*host*/, int nproblems, int mask_mode,
+                               const float* sprel_w, const float* sprel_b, int B, int NH, float scale, int dtype,
+                               void* stream);
+
 /* ---- LayerNorm over the last dim (wave reduction, fp32 statistics) -------------------------------
  * out = LN(x [+ residual]) * gamma + beta.  Replaces BertLayerNorm / nn.LayerNorm
  * (FT/vilmodel.py:73,170,176,210,216; FT/transformer.py:144-145,174,179; FT/ops.py:19).

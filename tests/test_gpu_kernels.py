@@ -101,6 +101,32 @@ def test_attention(K, dtype, B, nh, Nq, Nk, mode, sprel):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_attention_grouped(K, dtype):
+    """two branches of an x-layer in one launch == two launches (cross-attention on shared text K/V; self-attention
+    with the sprel bias on the first branch only)."""
+    B, nh, L = 5, 12, 80
+    H = nh * 64
+    kv = _r(B, L, 4 * H, seed=1, dtype=dtype)
+    tmask = (torch.arange(L)[None] < torch.tensor([80, 33, 1, 64, 17])[:, None]).cuda()
+    qs = [_r(B, 20, H, seed=2, dtype=dtype), _r(B, 70, H, seed=3, dtype=dtype)]
+    probs = [(qs[0], kv[..., :H], kv[..., H:2 * H], tmask, None), (qs[1], kv[..., 2 * H:3 * H], kv[..., 3 * H:], tmask, None)]
+    outs = K.attention_grouped(probs, nh, 1)
+    for (q, k, v, m, _), o in zip(probs, outs):
+        assert torch.equal(o, K.attention(q, k, v, nh, m, 1))
+    sw, sb = torch.tensor([-0.21]).cuda(), torch.tensor([0.07]).cuda()
+    probs = []
+    for j, N in enumerate((20, 38)):
+        qkv = _r(B, N, 3 * H, seed=4 + j, dtype=dtype)
+        m = (torch.arange(N)[None] < torch.tensor([N, 3, 1, N - 1, 9])[:, None]).cuda()
+        probs.append((qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], m, (_r(B, N, N, seed=7).abs() * 5) if j == 0 else None))
+    outs = K.attention_grouped(probs, nh, 1, sw, sb)
+    for (q, k, v, m, d), o in zip(probs, outs):
+        ref = _attn_ref(q, k, v, nh, m, 1, d, sw, sb)
+        assert torch.equal(o, K.attention(q, k, v, nh, m, 1, d, sw if d is not None else None, sb if d is not None else None))
+        assert (o.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [
     (4, 12, 20, 80, 1, False), (4, 12, 38, 38, 1, False), (4, 12, 20, 20, 1, True), (3, 12, 36, 36, 2, False),
     (3, 2, 108, 108, 3, False), (2, 12, 100, 250, 1, False), (3, 12, 1, 5, 0, False), (2, 2, 70, 130, 1, True),

@@ -9,16 +9,16 @@
 
 constexpr int ROWB = 128;
 // each block: `rows` tile rows per stage (rows/32 wave-instructions per wave, 4 waves), K sweep of nk stages
-template <int ROWS, int MODE, int NST, int ROT>
-__global__ __launch_bounds__(256) void ingest(const char* __restrict__ src, int ld_bytes, int nk, int npanel, unsigned* sink) {
+template <int ROWS, int MODE, int NST, int ROT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void ingest(const char* __restrict__ src, int ld_bytes, int nk, int npanel, unsigned* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int LPS = ROWS / 32, STAGE = ROWS * ROWB;
+  constexpr int LPS = ROWS / (8 * NW), STAGE = ROWS * ROWB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int panel = blockIdx.x % npanel;
   const char* p[LPS];
 #pragma unroll
   for (int i = 0; i < LPS; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
     p[i] = src + (size_t)(panel * ROWS + row) * ld_bytes + (lane & 7) * 16;
   }
   const int kofs = ROT ? (int)((blockIdx.x * 7u) % (unsigned)nk) : 0;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ src, int 
     auto issue = [&](int stage, int k) {
 #pragma unroll
       for (int i = 0; i < LPS; ++i) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + (i * 4 + wave) * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + (i * NW + wave) * 1024);
         const char* g = p[i] + (size_t)kk(k) * ROWB;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ src, int 
     for (int i = 0; i < LPS; ++i) r1[i] = *reinterpret_cast<const uint4*>(p[i] + (size_t)kk(1) * ROWB);
     for (int k = 0; k < nk; k += 2) {
 #pragma unroll
-      for (int i = 0; i < LPS; ++i) *reinterpret_cast<uint4*>(smem + (i * 4 + wave) * 1024 + lane * 16) = r0[i];
+      for (int i = 0; i < LPS; ++i) *reinterpret_cast<uint4*>(smem + (i * NW + wave) * 1024 + lane * 16) = r0[i];
       if (k + 2 < nk) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i) r0[i] = *reinterpret_cast<const uint4*>(p[i] + (size_t)kk(k + 2) * ROWB);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ src, int 
       __syncthreads();
       acc += *reinterpret_cast<const unsigned*>(smem + threadIdx.x * 4);
 #pragma unroll
-      for (int i = 0; i < LPS; ++i) *reinterpret_cast<uint4*>(smem + STAGE + (i * 4 + wave) * 1024 + lane * 16) = r1[i];
+      for (int i = 0; i < LPS; ++i) *reinterpret_cast<uint4*>(smem + STAGE + (i * NW + wave) * 1024 + lane * 16) = r1[i];
       if (k + 3 < nk) {
 #pragma unroll
         for (int i = 0; i < LPS; ++i) r1[i] = *reinterpret_cast<const uint4*>(p[i] + (size_t)kk(k + 3) * ROWB);
@@ -75,19 +75,19 @@ __global__ __launch_bounds__(256) void ingest(const char* __restrict__ src, int 
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int ROWS, int MODE, int NST, int ROT = 0>
+template <int ROWS, int MODE, int NST, int ROT = 0, int NW = 4>
 int run(const char* name, const char* src, int ld, int nk, int npanel, int blocks, int lds_pad, unsigned* sink) {
   const int smem = NST * ROWS * ROWB + lds_pad;
-  CK(hipFuncSetAttribute((const void*)ingest<ROWS, MODE, NST, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  CK(hipFuncSetAttribute((const void*)ingest<ROWS, MODE, NST, ROT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((ingest<ROWS, MODE, NST, ROT>), dim3(blocks), dim3(256), smem, 0, src, ld, nk, npanel, sink);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((ingest<ROWS, MODE, NST, ROT, NW>), dim3(blocks), dim3(NW * 64), smem, 0, src, ld, nk, npanel, sink);
   CK(hipEventRecord(e0));
   const int rep = 10;
-  for (int w = 0; w < rep; ++w) hipLaunchKernelGGL((ingest<ROWS, MODE, NST, ROT>), dim3(blocks), dim3(256), smem, 0, src, ld, nk, npanel, sink);
+  for (int w = 0; w < rep; ++w) hipLaunchKernelGGL((ingest<ROWS, MODE, NST, ROT, NW>), dim3(blocks), dim3(NW * 64), smem, 0, src, ld, nk, npanel, sink);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / rep, bytes = (double)blocks * nk * ROWS * ROWB;
-  printf("%-30s rot %d rows/stage %3d nst %d blocks %5d (lds %6d): %7.1f us  %6.2f TB/s  %5.1f B/clk/CU\n", name, ROT, ROWS, NST, blocks, smem, us,
+  printf("%-30s nw %d rot %d rows/stage %3d nst %d blocks %5d (lds %6d): %7.1f us  %6.2f TB/s  %5.1f B/clk/CU\n", name, NW, ROT, ROWS, NST, blocks, smem, us,
          bytes / us / 1e6, bytes / (us * 1e-6) / 2.4e9 / 256);
   return 0;
 }
@@ -96,23 +96,18 @@ int main() {
   const int K = 3072, ld = K * 2, nk = ld / ROWB, rows_total = 4480;   // x.ff2-like: 3712 + 768 rows of 6 KiB
   char* src; unsigned* sink;
   CK(hipMalloc(&src, (size_t)rows_total * ld)); CK(hipMemset(src, 1, (size_t)rows_total * ld)); CK(hipMalloc(&sink, 4));
-  const int np1 = rows_total / 128, np2 = rows_total / 256;
-  run<128, 0, 2>("dma  64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 0, 2, 1>("dma  64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 0, 3>("dma  64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 0, 3, 1>("dma  64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 1, 2>("regs 64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 1, 2, 1>("regs 64x64-like", src, ld, nk, np1, 696, 0, sink);
-  run<128, 0, 2, 1>("dma  64x64-like many", src, ld, nk, np1, 2048, 0, sink);
-  run<128, 1, 2, 1>("regs 64x64-like many", src, ld, nk, np1, 2048, 0, sink);
-  run<128, 0, 2, 1>("dma  64x64-like 2/CU", src, ld, nk, np1, 2048, 40 * 1024, sink);
-  run<128, 1, 2, 1>("regs 64x64-like 2/CU", src, ld, nk, np1, 2048, 40 * 1024, sink);
-  run<256, 0, 2>("dma  128x128-like", src, ld, nk, np2, 174, 0, sink);
-  run<256, 0, 2, 1>("dma  128x128-like", src, ld, nk, np2, 174, 0, sink);
-  run<256, 0, 3, 1>("dma  128x128-like", src, ld, nk, np2, 174, 0, sink);
-  run<256, 1, 2>("regs 128x128-like", src, ld, nk, np2, 174, 0, sink);
-  run<256, 1, 2, 1>("regs 128x128-like", src, ld, nk, np2, 174, 0, sink);
-  run<256, 0, 2, 1>("dma  128x128-like many", src, ld, nk, np2, 2048, 0, sink);
-  run<256, 1, 2, 1>("regs 128x128-like many", src, ld, nk, np2, 2048, 0, sink);
+  // everything L2-resident (2 panels shared by all workgroups): the pure L2 -> LDS rate of ONE workgroup per CU
+  run<256, 0, 2, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
+  run<256, 0, 3, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
+  run<256, 0, 4, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
+  run<256, 0, 3, 0, 8>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
+  run<512, 0, 2, 0, 8>("L2-hot 1/CU 512-row", src, ld, nk, 2, 174, 0, sink);
+  run<256, 0, 2, 0, 4>("L2-hot 2/CU", src, ld, nk, 2, 512, 0, sink);
+  run<128, 0, 2, 0, 4>("L2-hot 64x64-like 696", src, ld, nk, 2, 696, 0, sink);
+  run<128, 0, 2, 0, 4>("L2-hot 64x64-like 5/CU", src, ld, nk, 2, 1280, 0, sink);
+  run<128, 0, 3, 0, 4>("L2-hot 64x64-like 3/CU", src, ld, nk, 2, 768, 0, sink);
+  // GEMM-like sharing: 8 panels per XCD-group
+  run<256, 0, 2, 0, 4>("8 panels 1/CU", src, ld, nk, 8, 174, 0, sink);
+  run<256, 0, 3, 0, 4>("8 panels 1/CU", src, ld, nk, 8, 174, 0, sink);
   return 0;
 }
