@@ -59,6 +59,7 @@ SIGNATURES = {
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),
     'dsrg_act_bwd': (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     'dsrg_layernorm_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P]),
+    'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 

@@ -317,6 +317,72 @@ __global__ __launch_bounds__(64) void nav_logits_kernel(const float* __restrict_
   }
 }
 
+// ---- action selection + loss tail (agent.py:484-516): one wave per episode row of nav logits ([B,N], -inf = masked).
+//   probs = softmax(row); stop_prob = probs[0]; argmax (first maximum, like torch.max); entropy = -sum p log p;
+//   sample = inverse-CDF draw with the caller's uniform u[b]; CE row loss = lse - logit[target] (0 when target == ignore);
+//   dlogits = probs - onehot(target) (0 row when ignored): the gradient of the summed cross-entropy.
+__global__ __launch_bounds__(64) void action_tail_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ targets,
+                                                         int64_t ignore, const float* __restrict__ u, float* __restrict__ stop_prob,
+                                                         int32_t* __restrict__ amax, int32_t* __restrict__ sample,
+                                                         float* __restrict__ entropy, float* __restrict__ loss_rows,
+                                                         float* __restrict__ dlogits, int N) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* row = logits + (size_t)b * ld;
+  float mx = -INFINITY;
+  int ai = 0x7fffffff;
+  for (int j = lane; j < N; j += 64) {
+    const float v = row[j];
+    if (v > mx) { mx = v; ai = j; }              // strided scan keeps the first index of this lane's maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(ai, o);
+    if (om > mx || (om == mx && oi < ai)) { mx = om; ai = oi; }
+  }
+  float se = 0.f;
+  for (int j = lane; j < N; j += 64) se += __expf(row[j] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se), inv = 1.0f / se;
+  float ent = 0.f;
+  for (int j = lane; j < N; j += 64) {
+    const float v = row[j];
+    if (v > -INFINITY) { const float p = __expf(v - mx) * inv; ent -= p * (v - lse); }
+  }
+  ent = wave_sum(ent);
+  const int64_t t = targets ? targets[b] : ignore;
+  const bool live = targets && t != ignore && t >= 0 && t < N;
+  if (dlogits)
+    for (int j = lane; j < N; j += 64)
+      dlogits[(size_t)b * N + j] = live ? __expf(row[j] - mx) * inv - (j == (int)t ? 1.f : 0.f) : 0.f;
+  if (sample) {
+    // sequential inverse CDF over 64-wide chunks: pick the first j with cdf(j) > u (the last unmasked one if rounding
+    // leaves cdf(N-1) <= u)
+    const float uu = u[b];
+    float base = 0.f;
+    int pick = -1, lastpos = -1;
+    for (int j0 = 0; j0 < N && pick < 0; j0 += 64) {
+      const int j = j0 + lane;
+      const float p = j < N ? __expf(row[j] - mx) * inv : 0.f;
+      float c = p;                                  // inclusive scan across the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const float y = __shfl_up(c, o); if (lane >= o) c += y; }
+      c += base;
+      const unsigned long long hit = __ballot(p > 0.f && c > uu), pos = __ballot(p > 0.f);
+      if (pos) lastpos = j0 + 63 - __builtin_clzll(pos);
+      if (hit) pick = j0 + __builtin_ctzll(hit);
+      base = __shfl(c, 63);
+    }
+    if (lane == 0) sample[b] = pick >= 0 ? pick : lastpos;
+  }
+  if (lane == 0) {
+    stop_prob[b] = __expf(row[0] - mx) * inv;
+    amax[b] = ai;
+    if (entropy) entropy[b] = ent;
+    if (loss_rows) loss_rows[b] = live ? lse - row[t] : 0.f;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void igl_blend_kernel(const T* __restrict__ aug, const T* __restrict__ x, const float* __restrict__ wa,
                                                         const float* __restrict__ ba, const float* __restrict__ wo, const float* __restrict__ bo,
@@ -498,5 +564,18 @@ extern "C" int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* w
   if (dtype == DSRG_F32) hipLaunchKernelGGL((igl_blend_kernel<float>), grid, block, 0, s, (const float*)aug, (const float*)x, wa, ba, wo, bo, (float*)out, M, H);
   else hipLaunchKernelGGL((igl_blend_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)aug, (const bf16_t*)x, wa, ba, wo, bo, (bf16_t*)out, M, H);
   DSRG_LAUNCH_CHECK("dsrg_igl_blend_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_action_tail_fwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, const float* u,
+                                    float* stop_prob, int32_t* argmax, int32_t* sample, float* entropy, float* loss_rows,
+                                    float* dlogits, int B, int N, void* stream) {
+  DSRG_CHECK(logits && stop_prob && argmax && B >= 0 && N >= 1 && ld >= N, "dsrg_action_tail_fwd: bad arguments");
+  DSRG_CHECK(!sample || u, "dsrg_action_tail_fwd: sampling needs the uniform draws u[B]");
+  DSRG_CHECK(!(loss_rows || dlogits) || targets, "dsrg_action_tail_fwd: loss / gradient output needs targets");
+  if (B == 0) return DSRG_OK;
+  hipLaunchKernelGGL(action_tail_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ld, targets, ignore_index, u, stop_prob, argmax,
+                     sample, entropy, loss_rows, dlogits, N);
+  DSRG_LAUNCH_CHECK("dsrg_action_tail_fwd");
   return DSRG_OK;
 }

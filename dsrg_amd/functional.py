@@ -509,3 +509,35 @@ def igl_blend(aug, x, wa, ba, wo, bo):
         w = torch.sigmoid(a @ wa + ba + xf @ wo + bo)[..., None]
         return (w * a + (1 - w) * xf).to(x.dtype)
     return _call(K.igl_blend, aten, aug, x, wa, ba, wo, bo)
+
+
+# ----------------------------------------------------------------------------- action selection + loss tail (agent.py:484-516)
+class _ActionLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        o = K.action_tail(logits, targets, None, ignore_index, want_grad=True)
+        ctx.save_for_backward(o['dlogits'])
+        ctx.mark_non_differentiable(o['stop_prob'], o['argmax'], o['entropy'])
+        return o['loss_rows'].sum(), o['stop_prob'], o['argmax'], o['entropy']
+
+    @staticmethod
+    def backward(ctx, gl, *_):
+        (d,) = ctx.saved_tensors
+        return d * gl, None, None
+
+
+def action_tail(nav_logits, targets=None, u=None, ignore_index=-100):
+    """One kernel for what the rollout does with a step's logits: stop probability (softmax[:,0]), greedy action, entropy,
+    optionally an inverse-CDF sample for the caller's uniforms `u`, and with `targets` the summed cross-entropy
+    (CrossEntropyLoss(ignore_index, reduction='sum'), differentiable w.r.t. the logits).  Returns a dict."""
+    lg = nav_logits if nav_logits.dtype == torch.float32 else nav_logits.float()
+    if targets is not None and torch.is_grad_enabled() and lg.requires_grad:
+        loss, sp, am, ent = _ActionLossFn.apply(lg, targets, ignore_index)
+        out = {'loss': loss, 'stop_prob': sp, 'argmax': am, 'entropy': ent}
+        if u is not None:
+            out['sample'] = K.action_tail(lg.detach(), None, u)['sample']
+        return out
+    o = K.action_tail(lg.detach(), targets, u, ignore_index)
+    if targets is not None:
+        o['loss'] = o.pop('loss_rows').sum()
+    return o

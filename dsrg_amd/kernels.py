@@ -382,3 +382,29 @@ def layernorm_bwd(x, residual, gamma, dy, eps):
     _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
                                       _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')
     return dz, dg, db
+
+
+def action_tail(logits, targets=None, u=None, ignore_index=-100, want_grad=False):
+    """nav logits [B,N] fp32 (-inf masked) -> dict(stop_prob, argmax, entropy[, sample][, loss_rows][, dlogits])."""
+    lib = _lib.load()
+    _dev(logits)
+    if logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise _lib.DsrgHipError('action_tail: logits must be fp32 [B,N] with contiguous rows')
+    B, N = logits.shape
+    dev = logits.device
+    if targets is not None and (targets.dtype != torch.int64 or targets.shape != (B,) or not targets.is_contiguous()):
+        raise _lib.DsrgHipError('action_tail: targets must be contiguous int64 [B]')
+    if u is not None and (u.dtype != torch.float32 or u.shape != (B,) or not u.is_contiguous()):
+        raise _lib.DsrgHipError('action_tail: u must be contiguous fp32 [B]')
+    out = {'stop_prob': torch.empty(B, device=dev), 'argmax': torch.empty(B, device=dev, dtype=torch.int32),
+           'entropy': torch.empty(B, device=dev)}
+    if u is not None:
+        out['sample'] = torch.empty(B, device=dev, dtype=torch.int32)
+    if targets is not None:
+        out['loss_rows'] = torch.empty(B, device=dev)
+        if want_grad:
+            out['dlogits'] = torch.empty(B, N, device=dev)
+    _lib.check(lib.dsrg_action_tail_fwd(_p(logits), logits.stride(0), _p(targets), int(ignore_index), _p(u), _p(out['stop_prob']),
+                                        _p(out['argmax']), _p(out.get('sample')), _p(out['entropy']), _p(out.get('loss_rows')),
+                                        _p(out.get('dlogits')), B, N, _stream()), 'dsrg_action_tail_fwd')
+    return out

@@ -165,6 +165,16 @@ int dsrg_nav_logits_fwd(const float* g_raw, const float* l_raw, const float* fus
                         const int32_t* gmap_src, const uint8_t* bw_mask, float* global_logits,
                         float* local_logits, float* fused_logits, int B, int G, int Vp, void* stream);
 
+/* ---- action selection + loss tail of a rollout step -------------------------------
+ * One pass over the nav logits [B,N] (fp32, -inf = masked) replaces FT/r2r/agent.py:484 (softmax), :491 (stop
+ * probability = probs[:,0]), :502 (CrossEntropyLoss(ignore_index, reduction='sum'), agent_base.py:150), :508 (argmax),
+ * :511-514 (Categorical entropy / sample).  sample[b] = first j with cdf_b(j) > u[b] (the caller draws u ~ U[0,1), so
+ * the result is a deterministic function of u); loss_rows[b] = lse_b - logits[b,target_b] (0 if ignored), their sum is
+ * the reference's loss; dlogits = softmax - onehot(target) is its gradient.  Optional outputs may be NULL. */
+int dsrg_action_tail_fwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, const float* u,
+                         float* stop_prob, int32_t* argmax, int32_t* sample, float* entropy, float* loss_rows,
+                         float* dlogits, int B, int N, void* stream);
+
 /* ---- IGL gate: w = sigmoid(aug·wa + ba + x·wo + bo); out = w·aug + (1-w)·x --------------------------
  * FT/vilmodel.py:525-528.  aug/x/out [M,H] `dtype`; wa/wo fp32 [H]; ba/bo fp32 [1]. */
 int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo,

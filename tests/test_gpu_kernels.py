@@ -358,3 +358,42 @@ def test_dense_dropout_residual_ln_train_path():
     assert (y.float() - ref).abs().max().item() <= 3e-2
     assert (r.grad.float() - rr.grad).abs().max().item() <= 3e-2 * rr.grad.abs().max().item() + 1e-3
     assert torch.isfinite(w.grad).all() and torch.isfinite(b.grad).all() and x.grad.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('B,N', [(64, 20), (7, 100), (3, 1), (5, 250)])
+def test_action_tail(K, B, N):
+    """softmax / stop probability / argmax / entropy / summed cross-entropy and its gradient / inverse-CDF sample of the
+    rollout's action tail (agent.py:484-516) against the torch ops the reference calls."""
+    from dsrg_amd import functional as Fn
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    logits = (torch.randn(B, N, generator=g) * 3).cuda()
+    masked = (torch.rand(B, N, generator=g) < 0.3).cuda()
+    masked[:, 0] = False
+    logits = logits.masked_fill(masked, float('-inf'))
+    targets = torch.randint(0, N, (B,), generator=g).cuda()
+    targets = torch.where(masked.gather(1, targets[:, None])[:, 0], torch.zeros_like(targets), targets)
+    if B > 2:
+        targets[1] = -100
+    u = torch.rand(B, generator=g).cuda()
+    lg = logits.clone().requires_grad_(True)
+    o = Fn.action_tail(lg, targets, u)
+    ref_l = logits.clone().requires_grad_(True)
+    probs = torch.softmax(ref_l, 1)
+    loss = torch.nn.functional.cross_entropy(ref_l, targets, ignore_index=-100, reduction='sum')
+    assert abs(o['loss'].item() - loss.item()) <= 1e-4 * max(1.0, abs(loss.item()))
+    assert (o['stop_prob'] - probs[:, 0]).abs().max().item() <= 1e-6
+    assert torch.equal(o['argmax'].long(), ref_l.max(1)[1])
+    ent = torch.distributions.Categorical(probs).entropy()
+    assert (o['entropy'] - ent).abs().max().item() <= 1e-5
+    (o['loss'] * 0.5).backward()
+    (loss * 0.5).backward()
+    assert (lg.grad - ref_l.grad).abs().max().item() <= 1e-6
+    cdf = probs.detach().double().cumsum(1)
+    smp = o['sample'].long()
+    assert (probs.detach().gather(1, smp[:, None])[:, 0] > 0).all()
+    hi = cdf.gather(1, smp[:, None])[:, 0]
+    lo = hi - probs.detach().double().gather(1, smp[:, None])[:, 0]
+    assert ((u.double() < hi + 1e-6) & (u.double() >= lo - 1e-6)).all()
+    # inference form: no targets, no gradient
+    o2 = Fn.action_tail(logits)
+    assert torch.equal(o2['argmax'], o['argmax']) and 'loss' not in o2

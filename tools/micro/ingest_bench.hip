@@ -47,6 +47,40 @@ __global__ __launch_bounds__(NW * 64) void ingest(const char* __restrict__ src, 
       acc += *reinterpret_cast<const unsigned*>(smem + cur * STAGE + threadIdx.x * 4);   // touch the stage
       cur = cur == NST - 1 ? 0 : cur + 1;
     }
+  } else if (MODE == 2) {
+    constexpr int PFD = 3;
+    auto issue = [&](int stage, int k) {
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE + (i * NW + wave) * 1024);
+        const char* g = p[i] + (size_t)kk(k) * ROWB;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+      }
+    };
+    // prefetcher lanes: waves with wave*64 < ROWS, lane l -> row wave*64+l, one dword of the line of K-step k
+    const bool pfw = wave * 64 < ROWS;
+    const char* prow = src + (size_t)(panel * ROWS + (wave * 64 + lane) % ROWS) * ld_bytes;
+    // The prefetch load lands asynchronously: its destination register must stay reserved until the final
+    // s_waitcnt, so every asm below takes it as a read-write operand (one live range for the whole loop).
+    unsigned dummy = 0;
+    issue(0, 0);
+    if (pfw) asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(prow) : "memory");
+    int cur = 0;
+    for (int k = 0; k < nk; ++k) {
+      if (pfw) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (k + 1 < nk) issue(cur ^ 1, k + 1);
+      if (pfw) {
+        const char* g = prow + (size_t)kk(k + PFD < nk ? k + PFD : nk - 1) * ROWB;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(g) : "memory");
+      }
+      acc += *reinterpret_cast<const unsigned*>(smem + cur * STAGE + threadIdx.x * 4);
+      cur ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy) :: "memory");
+    acc += dummy & 1;
   } else {
     uint4 r0[LPS], r1[LPS];
 #pragma unroll
@@ -96,18 +130,12 @@ int main() {
   const int K = 3072, ld = K * 2, nk = ld / ROWB, rows_total = 4480;   // x.ff2-like: 3712 + 768 rows of 6 KiB
   char* src; unsigned* sink;
   CK(hipMalloc(&src, (size_t)rows_total * ld)); CK(hipMemset(src, 1, (size_t)rows_total * ld)); CK(hipMalloc(&sink, 4));
-  // everything L2-resident (2 panels shared by all workgroups): the pure L2 -> LDS rate of ONE workgroup per CU
-  run<256, 0, 2, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
-  run<256, 0, 3, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
-  run<256, 0, 4, 0, 4>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
-  run<256, 0, 3, 0, 8>("L2-hot 1/CU", src, ld, nk, 2, 174, 0, sink);
-  run<512, 0, 2, 0, 8>("L2-hot 1/CU 512-row", src, ld, nk, 2, 174, 0, sink);
-  run<256, 0, 2, 0, 4>("L2-hot 2/CU", src, ld, nk, 2, 512, 0, sink);
-  run<128, 0, 2, 0, 4>("L2-hot 64x64-like 696", src, ld, nk, 2, 696, 0, sink);
-  run<128, 0, 2, 0, 4>("L2-hot 64x64-like 5/CU", src, ld, nk, 2, 1280, 0, sink);
-  run<128, 0, 3, 0, 4>("L2-hot 64x64-like 3/CU", src, ld, nk, 2, 768, 0, sink);
-  // GEMM-like sharing: 8 panels per XCD-group
-  run<256, 0, 2, 0, 4>("8 panels 1/CU", src, ld, nk, 8, 174, 0, sink);
-  run<256, 0, 3, 0, 4>("8 panels 1/CU", src, ld, nk, 8, 174, 0, sink);
+  const int np1 = rows_total / 128;
+  run<128, 0, 2, 0, 4>("dma", src, ld, nk, np1, 696, 0, sink);
+  run<128, 2, 2, 0, 4>("dma + L2 prefetch", src, ld, nk, np1, 696, 0, sink);
+  run<128, 0, 2, 0, 4>("dma L2-hot", src, ld, nk, 2, 696, 0, sink);
+  run<128, 2, 2, 0, 4>("dma + L2 prefetch, L2-hot", src, ld, nk, 2, 696, 0, sink);
+  run<256, 0, 2, 0, 4>("dma 128x128-like 348", src, ld, nk, rows_total / 256, 348, 0, sink);
+  run<256, 2, 2, 0, 4>("dma + L2 prefetch 128x128-like 348", src, ld, nk, rows_total / 256, 348, 0, sink);
   return 0;
 }
