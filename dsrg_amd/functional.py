@@ -226,7 +226,7 @@ class _LinearFn(torch.autograd.Function):
             if dy is None:
                 items.append(None)
                 continue
-            dy2 = _as2d(dy if dy.stride(-1) == 1 else dy.contiguous())
+            dy2 = _as2d(K.rows_ok(dy))
             if dy2.dtype != w.dtype:
                 dy2 = dy2.to(w.dtype)
             items.append((_as2d(x), w, dy2, ctx.needs_input_grad[2 + 4 * i], ctx.needs_input_grad[3 + 4 * i],

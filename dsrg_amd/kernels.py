@@ -26,6 +26,18 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def rows_ok(t):
+    """t as-is if its leading dims collapse onto one row stride (what every row kernel needs), else a contiguous copy:
+    incoming gradients can be arbitrary views (e.g. the slice of a longer token sequence)."""
+    if t.stride(-1) != 1:
+        return t.contiguous()
+    try:
+        _rows(t)
+        return t
+    except _lib.DsrgHipError:
+        return t.contiguous()
+
+
 def _dev(t):
     if not t.is_cuda:
         raise _lib.DsrgHipError('dsrg_amd kernels need device tensors (got %s); there is no CPU path' % t.device)
@@ -374,7 +386,7 @@ def layernorm_bwd(x, residual, gamma, dy, eps):
     _dev(x)
     M, ldx = _rows(x)
     H = x.shape[-1]
-    dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+    dy = rows_ok(dy)
     dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
     dgb = torch.zeros(2, H, device=x.device, dtype=torch.float32)
     dg, db = dgb[0], dgb[1]

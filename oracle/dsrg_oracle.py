@@ -248,9 +248,10 @@ def forward_navigation(sd, cfg, b):
             'fused_logits': fused, 'obj_logits': ol, 'txt_embeds': txt, 'cls_embeds': cls}
 
 
-def forward(sd, cfg, mode, batch, reverie=False):
-    """VLNBert.forward / GlocalTextPathNavCMT.forward dispatch, FT/model.py:21-41, FT/vilmodel.py:838-858."""
-    with torch.no_grad():
+def forward(sd, cfg, mode, batch, reverie=False, grad=False):
+    """VLNBert.forward / GlocalTextPathNavCMT.forward dispatch, FT/model.py:21-41, FT/vilmodel.py:838-858.
+    grad=True keeps the autograd graph (gradient parity tests differentiate the oracle)."""
+    with torch.set_grad_enabled(bool(grad)):
         if mode == 'language':
             return forward_text(sd, cfg, batch, reverie)
         if mode == 'panorama':

@@ -98,3 +98,37 @@ def compare(out, gold, tol, logit_tol=None, check_argmax=True, steps=3):
         for t in range(steps):
             assert (out['s%d_argmax' % t] == gold['s%d_argmax' % t]).all(), 'argmax step %d' % t
     return errs
+
+
+def chain_loss(fwd, meta, device='cpu', steps=2, B=4):
+    """Fine-tuning loss of a short rollout as the agent accumulates it (agent.py:502,578): sum over steps of
+    CrossEntropyLoss(ignore_index=-100, reduction='sum') on the fused logits, with the RMF memory and the panorama
+    embeddings carried from step to step INSIDE the autograd graph.  Targets are a fixed function of the -inf pattern."""
+    _, L, G, O, seed, reverie, No = [int(x) for x in meta]
+    reverie = bool(reverie)
+    lb = synth.language_batch(B, L, seed)
+    txt = fwd('language', to_t(lb, device))
+    cls, loss = None, 0.0
+    for t in range(steps):
+        pb = synth.panorama_batch(B, 36, O, seed + 10 * t, reverie=reverie, No=No)
+        pe, pm, pf = fwd('panorama', to_t(pb, device))
+        Vp = pe.shape[1] + 2
+        vlens = pm.sum(1).cpu().numpy() + 2
+        nb = to_t(synth.navigation_batch(B, G, Vp, seed + 10 * t, ncand=pb['ncand'], nav_types=pb['nav_types'],
+                                         vp_lens=vlens, reverie=reverie), device)
+        mem = torch.zeros(B, 768, device=device, dtype=pe.dtype) if cls is None else cls
+        nb['vp_img_embeds'] = torch.cat([torch.zeros(B, 1, 768, device=device, dtype=pe.dtype), mem[:, None], pe], 1)
+        g = nb['gmap_img_embeds'].to(pe.dtype)
+        nb['gmap_img_embeds'] = torch.cat([g[:, :1], mem[:, None], pf[:, None], g[:, 3:]], 1)
+        nb['txt_embeds'], nb['txt_masks'] = txt, torch.from_numpy(lb['txt_masks']).to(device)
+        o = fwd('navigation', nb)
+        cls = o['cls_embeds']
+        fl = o['fused_logits'].float()
+        fin = torch.isfinite(fl.detach())
+        order = torch.argsort((~fin).int(), dim=1, stable=True)            # finite positions first, in index order
+        pick = (torch.arange(B, device=fl.device) + t) % fin.sum(1)
+        tgt = order.gather(1, pick[:, None])[:, 0]
+        if B > 2:
+            tgt[B - 1] = -100
+        loss = loss + torch.nn.functional.cross_entropy(fl, tgt, ignore_index=-100, reduction='sum')
+    return loss
