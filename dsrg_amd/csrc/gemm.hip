@@ -277,7 +277,15 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
   a.gm = gm_env ? atoi(gm_env) : 4;
   if (a.gm < 1) a.gm = 1;
-  const int nst = g_nst_override;       // tuning aid only; the shipped ring depth is 2
+  // Ring depth: 2 keeps the most workgroups per CU and wins whenever a CU holds >= 2 tiles; with <= ~1.7 tiles per CU
+  // and a long K loop (the FFN-out projections of the panorama / object encoders) a lone workgroup cannot cover the
+  // L2 latency with one stage in flight, and a 3-deep ring is 17-30 % faster (tools/bench_gemm.py).
+  int nst = g_nst_override;
+  if (nst == 0 && bm == 64 && bn == 64 && tiles <= 512) {
+    int minK = 1 << 30;
+    for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
+    if (minK >= 1024) nst = 3;
+  }
   if (bm == 128) {
     if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
     return launch<T, OutT, 128, 128, 2>(a, tiles, s);
@@ -287,6 +295,7 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
     return launch<T, OutT, 64, 128, 2>(a, tiles, s);
   }
   if (nst == 3) return launch<T, OutT, 64, 64, 3>(a, tiles, s);
+  if (nst == 4) return launch<T, OutT, 64, 64, 4>(a, tiles, s);
   return launch<T, OutT, 64, 64, 2>(a, tiles, s);
 }
 

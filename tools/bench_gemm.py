@@ -16,6 +16,10 @@ SHAPES = [  # name, [(M,N,K)...] grouped, act, out_f32, residual
     ('pano.ff2    M=2304 N=768 K=3072 +res', [(2304, 768, 3072)], 0, False, True),
     ('obj.ff1     M=6912 N=3072 K=128', [(6912, 3072, 128)], 1, False, False),
     ('obj.ff2     M=6912 N=128 K=3072 f32out+res', [(6912, 128, 3072)], 0, True, True),
+    ('his_map     M=64 N=768 K=2304 f32out', [(64, 768, 2304)], 0, True, False),
+    ('poolers     3x M=64 N=768 K=768 tanh', [(64, 768, 768)] * 3, 3, False, False),
+    ('heads       g,l,fuse l1 relu f32out', [(1280, 768, 768), (2432, 768, 768), (64, 768, 1536)], 2, True, False),
+    ('img_linear  M=2304 N=768 K=768 f32out', [(2304, 768, 768)], 0, True, False),
     ('txtkv       M=5120 N=12288 K=768', [(5120, 12288, 768)], 0, False, False),
     ('square 4096', [(4096, 4096, 4096)], 0, False, False),
 ]
