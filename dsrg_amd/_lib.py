@@ -59,6 +59,11 @@ SIGNATURES = {
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),
     'dsrg_act_bwd': (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
     'dsrg_layernorm_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P]),
+    'dsrg_group_mean_bwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'dsrg_gaa_pool_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'dsrg_head_tail_bwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    'dsrg_nav_logits_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_igl_blend_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }

@@ -1,0 +1,364 @@
+// Backward of the row kernels of rowops.hip (training path): ASV group mean, GAA pooling, ClsPrediction tail,
+// dynamic logit fusion, IGL gate and the token-embedding sums.  Same ownership as the forward (one wave per row /
+// one workgroup per episode); parameter gradients are summed per workgroup (registers -> LDS) and leave as ONE float
+// atomic per element per workgroup into zeroed fp32 buffers.  All arithmetic fp32, forward values are recomputed.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 4;       // float4 per lane: H <= 1024
+constexpr int WPB = 4;
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float hsum(float4 a) { return a.x + a.y + a.z + a.w; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void lds_add4(float* p, float4 v) { atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w); }
+
+#define ROWV(i, c) for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; if (i < nv && c < H)
+#define ENDV }
+
+// normalise a row in place: v <- (v - mean) * rstd, returns rstd
+__device__ __forceinline__ float ln_hat(float4 (&v)[MAXV], int nv, int lane, int H, float eps) {
+  float s = 0.f;
+#pragma unroll
+  ROWV(i, c) s += hsum(v[i]); ENDV
+  const float mean = wave_sum(s) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  ROWV(i, c) { v[i] = v[i] - f4(mean); ss += dot4(v[i], v[i]); } ENDV
+  const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+  ROWV(i, c) v[i] = rstd * v[i]; ENDV
+  return rstd;
+}
+
+// dz of LayerNorm given g = dy*gamma and the normalised row zh:  rstd * (g - mean(g) - zh * mean(g*zh))
+__device__ __forceinline__ void ln_dz(float4 (&g)[MAXV], const float4 (&zh)[MAXV], float rstd, int nv, int lane, int H) {
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  ROWV(i, c) { a += hsum(g[i]); b += dot4(g[i], zh[i]); } ENDV
+  a = wave_sum(a) / (float)H;
+  b = wave_sum(b) / (float)H;
+#pragma unroll
+  ROWV(i, c) g[i] = rstd * (g[i] - f4(a) - b * zh[i]); ENDV
+}
+
+// ---- ASV group mean: dx[m*G+g, :] = dy[m, :] / G
+template <typename T>
+__global__ __launch_bounds__(256) void group_mean_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int M, int G, int H) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, hv = H / 4;
+  if (idx >= M * G * hv) return;
+  const int r = idx / hv, c = (idx % hv) * 4;
+  const float4 g = ld4(dy + (size_t)(r / G) * lddy + c);
+  st4(dx + (size_t)r * lddx + c, (1.0f / (float)G) * g);
+}
+
+// ---- GAA pooling backward: a = softmax_v(tanh(x_v.w + b)), out = sum_v a_v x_v
+//   da_v = dout.x_v;  dt_v = a_v (da_v - sum_u a_u da_u);  ds_v = dt_v (1 - t_v^2);  dx_v = a_v dout + ds_v w
+//   dw = sum_{b,v} ds_v x_v;  db = sum ds_v.   One 16-wave workgroup per episode, rows held in registers (V <= 64).
+constexpr int GWAVES = 16, GVPW = 4;
+template <typename T>
+__global__ __launch_bounds__(1024) void gaa_pool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const T* __restrict__ dout, T* __restrict__ dx, float* __restrict__ dw,
+                                                            float* __restrict__ db, int V, int H) {
+  __shared__ float tv[64], av[64], da[64];
+  extern __shared__ __attribute__((aligned(16))) float part[];      // [H] workgroup sum of ds_v x_v
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (H + 255) / 256;
+  const T* xb = x + (size_t)b * V * H;
+  float4 row[GVPW][MAXV], ww[MAXV], go[MAXV];
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = wave + GWAVES * r, c = (i * 64 + lane) * 4;
+      row[r][i] = (v < V && i < nv && c < H) ? ld4(xb + (size_t)v * H + c) : f4(0.f);
+    }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const bool ok = i < nv && c < H;
+    ww[i] = ok ? *reinterpret_cast<const float4*>(w + c) : f4(0.f);
+    go[i] = ok ? ld4(dout + (size_t)b * H + c) : f4(0.f);
+  }
+  for (int c = threadIdx.x; c < H; c += 1024) part[c] = 0.f;
+  const float b0 = bias[0];
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r) {
+    const int v = wave + GWAVES * r;
+    float s = 0.f, d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { s += dot4(row[r][i], ww[i]); d += dot4(row[r][i], go[i]); }
+    s = wave_sum(s); d = wave_sum(d);
+    if (lane == 0 && v < V) { tv[v] = tanhf(s + b0); da[v] = d; }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int v = 0; v < V; ++v) mx = fmaxf(mx, tv[v]);
+  float den = 0.f;
+  for (int v = 0; v < V; ++v) den += expf(tv[v] - mx);
+  const float inv = 1.0f / den;
+  float mean_da = 0.f;
+  for (int v = 0; v < V; ++v) mean_da += expf(tv[v] - mx) * inv * da[v];
+  float4 accw[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) accw[i] = f4(0.f);
+  float dbs = 0.f;
+#pragma unroll
+  for (int r = 0; r < GVPW; ++r) {
+    const int v = wave + GWAVES * r;
+    if (v >= V) continue;
+    const float a = expf(tv[v] - mx) * inv, t = tv[v];
+    const float ds = a * (da[v] - mean_da) * (1.f - t * t);
+    dbs += ds;
+#pragma unroll
+    ROWV(i, c) {
+      st4(dx + ((size_t)b * V + v) * H + c, a * go[i] + ds * ww[i]);
+      accw[i] = accw[i] + ds * row[r][i];
+    } ENDV
+  }
+#pragma unroll
+  ROWV(i, c) lds_add4(part + c, accw[i]); ENDV
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 1024) atomicAdd(dw + c, part[c]);
+  if (lane == 0 && dbs != 0.f) atomicAdd(db, dbs);
+}
+
+// ---- ClsPrediction tail backward: score = (LN(h) * gamma + beta) . w2 + b2
+template <bool UNUSED = false>
+__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ w2,
+                                                            const float* __restrict__ dscore, float eps, float* __restrict__ dh, int lddh,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dw2,
+                                                            float* __restrict__ db2, int M, int H, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];       // [3][H]: dgamma, dbeta, dw2
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = (H + 255) / 256;
+  for (int c = threadIdx.x; c < 3 * H; c += 256) acc[c] = 0.f;
+  __syncthreads();
+  float4 gm[MAXV], bt[MAXV], wv[MAXV], ag[MAXV], ab[MAXV], aw[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const bool ok = i < nv && c < H;
+    gm[i] = ok ? *reinterpret_cast<const float4*>(gamma + c) : f4(0.f);
+    bt[i] = ok ? *reinterpret_cast<const float4*>(beta + c) : f4(0.f);
+    wv[i] = ok ? *reinterpret_cast<const float4*>(w2 + c) : f4(0.f);
+    ag[i] = ab[i] = aw[i] = f4(0.f);
+  }
+  float sds = 0.f;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  for (int row = m0 + wave; row < m1; row += WPB) {
+    float4 zh[MAXV], g[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      zh[i] = (i < nv && c < H) ? ld4(h + (size_t)row * ldh + c) : f4(0.f);
+    }
+    const float rstd = ln_hat(zh, nv, lane, H, eps);
+    const float ds = dscore[row];
+    sds += ds;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const float4 dy = ds * wv[i];
+      g[i] = dy * gm[i];
+      ag[i] = ag[i] + dy * zh[i];
+      ab[i] = ab[i] + dy;
+      aw[i] = aw[i] + ds * (zh[i] * gm[i] + bt[i]);
+    }
+    ln_dz(g, zh, rstd, nv, lane, H);
+#pragma unroll
+    ROWV(i, c) st4(dh + (size_t)row * lddh + c, g[i]); ENDV
+  }
+#pragma unroll
+  ROWV(i, c) { lds_add4(acc + c, ag[i]); lds_add4(acc + H + c, ab[i]); lds_add4(acc + 2 * H + c, aw[i]); } ENDV
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    atomicAdd(dgamma + c, acc[c]); atomicAdd(dbeta + c, acc[H + c]); atomicAdd(dw2 + c, acc[2 * H + c]);
+  }
+  if (lane == 0 && sds != 0.f) atomicAdd(db2, sds);
+}
+
+// ---- dynamic fusion + logit fusion backward (forward: nav_logits_kernel, rowops.hip)
+//   gl_j = g_j fw (masked -> -inf),  ll_k = l_k (1 - fw) (masked -> -inf),  fl_j = gl_j + [j = 0] ll_0 + [src_j >= 0] ll_src_j
+//   + [src_j = -2] sum_{k: bw_k} ll_k  (j >= 1 for the two src terms).  One wave per episode.
+constexpr int NAV_MAX = 1024;
+__global__ __launch_bounds__(64) void nav_logits_bwd_kernel(const float* __restrict__ g_raw, const float* __restrict__ l_raw,
+                                                            const float* __restrict__ fuse_raw, const uint8_t* __restrict__ gmask,
+                                                            const uint8_t* __restrict__ gvis, const uint8_t* __restrict__ vnav,
+                                                            const int32_t* __restrict__ gsrc, const uint8_t* __restrict__ bwm,
+                                                            const float* __restrict__ dgl, const float* __restrict__ dll,
+                                                            const float* __restrict__ dfl, float* __restrict__ dg_raw,
+                                                            float* __restrict__ dl_raw, float* __restrict__ dfuse_raw, int G, int Vp) {
+  __shared__ float dl_acc[NAV_MAX];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float fw = fuse_raw ? 1.0f / (1.0f + expf(-fuse_raw[b])) : 0.5f;
+  for (int k = lane; k < Vp; k += 64) dl_acc[k] = 0.f;
+  __syncthreads();
+  float bws = 0.f, dfw = 0.f;
+  for (int j = lane; j < G; j += 64) {
+    const size_t o = (size_t)b * G + j;
+    const bool dead = gvis[o] || !gmask[o];
+    const float df = dfl ? dfl[o] : 0.f;
+    const float dg = dead ? 0.f : (dgl ? dgl[o] : 0.f) + df;      // masked_fill: no gradient through a masked gl
+    dg_raw[o] = dg * fw;
+    dfw += dg * g_raw[o];
+    if (j == 0) atomicAdd(&dl_acc[0], df);
+    else {
+      const int s = gsrc[o];
+      if (s >= 0 && s < Vp) atomicAdd(&dl_acc[s], df);
+      else if (s == -2) bws += df;
+    }
+  }
+  bws = wave_sum(bws);
+  __syncthreads();
+  for (int k = lane; k < Vp; k += 64) {
+    const size_t o = (size_t)b * Vp + k;
+    const float d = vnav[o] ? (dll ? dll[o] : 0.f) + dl_acc[k] + (bwm[o] ? bws : 0.f) : 0.f;
+    dl_raw[o] = d * (1.0f - fw);
+    dfw -= d * l_raw[o];
+  }
+  dfw = wave_sum(dfw);
+  if (lane == 0 && dfuse_raw) dfuse_raw[b] = dfw * fw * (1.0f - fw);
+}
+
+// ---- IGL gate backward: w = sigmoid(aug.wa + ba + x.wo + bo), out = w aug + (1 - w) x
+template <typename T>
+__global__ __launch_bounds__(256) void igl_blend_bwd_kernel(const T* __restrict__ aug, const T* __restrict__ x, const float* __restrict__ wa,
+                                                            const float* __restrict__ ba, const float* __restrict__ wo,
+                                                            const float* __restrict__ bo, const T* __restrict__ dout, T* __restrict__ daug,
+                                                            T* __restrict__ dx, float* __restrict__ dwa, float* __restrict__ dwo,
+                                                            float* __restrict__ dbias /*[2]: dba, dbo*/, int M, int H, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];       // [2][H]: dwa, dwo
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = (H + 255) / 256;
+  for (int c = threadIdx.x; c < 2 * H; c += 256) acc[c] = 0.f;
+  __syncthreads();
+  float4 a4[MAXV], o4[MAXV], ga[MAXV], go[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const bool ok = i < nv && c < H;
+    a4[i] = ok ? *reinterpret_cast<const float4*>(wa + c) : f4(0.f);
+    o4[i] = ok ? *reinterpret_cast<const float4*>(wo + c) : f4(0.f);
+    ga[i] = go[i] = f4(0.f);
+  }
+  const float bsum = ba[0] + bo[0];
+  float sds = 0.f;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  for (int row = m0 + wave; row < m1; row += WPB) {
+    float4 va[MAXV], vx[MAXV], gd[MAXV];
+    float s = 0.f, dwg = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const bool ok = i < nv && c < H;
+      va[i] = ok ? ld4(aug + (size_t)row * H + c) : f4(0.f);
+      vx[i] = ok ? ld4(x + (size_t)row * H + c) : f4(0.f);
+      gd[i] = ok ? ld4(dout + (size_t)row * H + c) : f4(0.f);
+      s += dot4(va[i], a4[i]) + dot4(vx[i], o4[i]);
+      dwg += dot4(gd[i], va[i] - vx[i]);
+    }
+    s = wave_sum(s) + bsum;
+    const float w = 1.0f / (1.0f + expf(-s));
+    const float ds = wave_sum(dwg) * w * (1.f - w);
+    sds += ds;
+#pragma unroll
+    ROWV(i, c) {
+      st4(daug + (size_t)row * H + c, w * gd[i] + ds * a4[i]);
+      st4(dx + (size_t)row * H + c, (1.f - w) * gd[i] + ds * o4[i]);
+      ga[i] = ga[i] + ds * va[i];
+      go[i] = go[i] + ds * vx[i];
+    } ENDV
+  }
+#pragma unroll
+  ROWV(i, c) { lds_add4(acc + c, ga[i]); lds_add4(acc + H + c, go[i]); } ENDV
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(dwa + c, acc[c]); atomicAdd(dwo + c, acc[H + c]); }
+  if (lane == 0 && sds != 0.f) { atomicAdd(dbias, sds); atomicAdd(dbias + 1, sds); }
+}
+
+inline bool okdt(int d) { return d == DSRG_F32 || d == DSRG_BF16; }
+inline bool al(const void* p, uintptr_t m) { return ((uintptr_t)p & m) == 0; }
+inline int strip(int M) { int r = (M + 511) / 512; return r < WPB ? WPB : (r + WPB - 1) / WPB * WPB; }   // <= ~512 workgroups
+
+}  // namespace
+
+extern "C" int dsrg_group_mean_bwd(const void* dy, int lddy, void* dx, int lddx, int M, int G, int H, int dtype, void* stream) {
+  DSRG_CHECK(dy && dx && okdt(dtype) && M >= 0 && G >= 1 && H > 0 && H % 4 == 0 && lddy >= H && lddx >= H && lddy % 4 == 0 && lddx % 4 == 0,
+             "dsrg_group_mean_bwd: bad arguments");
+  DSRG_CHECK(al(dy, dtype == DSRG_BF16 ? 7 : 15) && al(dx, dtype == DSRG_BF16 ? 7 : 15), "dsrg_group_mean_bwd: misaligned pointer");
+  if (M == 0) return DSRG_OK;
+  const long n = (long)M * G * (H / 4);
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((group_mean_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, M, G, H);
+  else hipLaunchKernelGGL((group_mean_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, M, G, H);
+  DSRG_LAUNCH_CHECK("dsrg_group_mean_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_gaa_pool_bwd(const void* x, const float* w, const float* bias, const void* dout, void* dx, float* dw, float* db,
+                                 int B, int V, int H, int dtype, void* stream) {
+  DSRG_CHECK(okdt(dtype) && x && w && bias && dout && dx && dw && db, "dsrg_gaa_pool_bwd: bad dtype or null pointer");
+  DSRG_CHECK(V >= 1 && V <= 64 && H > 0 && H % 4 == 0 && H <= 1024, "dsrg_gaa_pool_bwd: need 1 <= V <= 64 (got %d), H %% 4 == 0 and H <= 1024", V);
+  DSRG_CHECK(al(x, 15) && al(dout, 15) && al(dx, 15) && al(w, 15), "dsrg_gaa_pool_bwd: misaligned pointer");
+  if (B <= 0) return DSRG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DSRG_F32)
+    hipLaunchKernelGGL((gaa_pool_bwd_kernel<float>), dim3(B), dim3(1024), (size_t)H * 4, s, (const float*)x, w, bias, (const float*)dout, (float*)dx, dw, db, V, H);
+  else
+    hipLaunchKernelGGL((gaa_pool_bwd_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)H * 4, s, (const bf16_t*)x, w, bias, (const bf16_t*)dout, (bf16_t*)dx, dw, db, V, H);
+  DSRG_LAUNCH_CHECK("dsrg_gaa_pool_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_head_tail_bwd(const float* h, int ldh, const float* gamma, const float* beta, const float* w2, const float* dscore,
+                                  float eps, float* dh, int lddh, float* dgamma, float* dbeta, float* dw2, float* db2, int M, int H,
+                                  void* stream) {
+  DSRG_CHECK(h && gamma && beta && w2 && dscore && dh && dgamma && dbeta && dw2 && db2, "dsrg_head_tail_bwd: null pointer");
+  DSRG_CHECK(M >= 0 && H > 0 && H <= 1024 && H % 64 == 0 && ldh >= H && lddh >= H && ldh % 4 == 0 && lddh % 4 == 0, "dsrg_head_tail_bwd: bad dims");
+  DSRG_CHECK(al(h, 15) && al(dh, 15) && al(gamma, 15) && al(beta, 15) && al(w2, 15), "dsrg_head_tail_bwd: misaligned pointer");
+  if (M == 0) return DSRG_OK;
+  const int rpb = strip(M);
+  hipLaunchKernelGGL((head_tail_bwd_kernel<false>), dim3((M + rpb - 1) / rpb), dim3(256), (size_t)3 * H * 4, (hipStream_t)stream, h, ldh, gamma, beta,
+                     w2, dscore, eps, dh, lddh, dgamma, dbeta, dw2, db2, M, H, rpb);
+  DSRG_LAUNCH_CHECK("dsrg_head_tail_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_nav_logits_bwd(const float* g_raw, const float* l_raw, const float* fuse_raw, const uint8_t* gmap_masks,
+                                   const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const int32_t* gmap_src,
+                                   const uint8_t* bw_mask, const float* dglobal, const float* dlocal, const float* dfused,
+                                   float* dg_raw, float* dl_raw, float* dfuse_raw, int B, int G, int Vp, void* stream) {
+  DSRG_CHECK(g_raw && l_raw && gmap_masks && gmap_visited && vp_nav_masks && gmap_src && bw_mask && dg_raw && dl_raw,
+             "dsrg_nav_logits_bwd: null pointer");
+  DSRG_CHECK(B >= 0 && G >= 1 && Vp >= 1 && Vp <= NAV_MAX, "dsrg_nav_logits_bwd: bad dims (Vp <= %d)", NAV_MAX);
+  DSRG_CHECK(!fuse_raw == !dfuse_raw, "dsrg_nav_logits_bwd: fuse_raw and dfuse_raw go together");
+  if (B == 0) return DSRG_OK;
+  hipLaunchKernelGGL(nav_logits_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited,
+                     vp_nav_masks, gmap_src, bw_mask, dglobal, dlocal, dfused, dg_raw, dl_raw, dfuse_raw, G, Vp);
+  DSRG_LAUNCH_CHECK("dsrg_nav_logits_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_igl_blend_bwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo, const float* bo,
+                                  const void* dout, void* daug, void* dx, float* dwa, float* dwo, float* dbias, int M, int H, int dtype,
+                                  void* stream) {
+  DSRG_CHECK(okdt(dtype) && aug && x && wa && ba && wo && bo && dout && daug && dx && dwa && dwo && dbias, "dsrg_igl_blend_bwd: bad dtype or null pointer");
+  DSRG_CHECK(M >= 0 && H > 0 && H <= 1024 && H % 64 == 0, "dsrg_igl_blend_bwd: bad dims");
+  const uintptr_t m = dtype == DSRG_BF16 ? 7 : 15;
+  DSRG_CHECK(al(aug, m) && al(x, m) && al(dout, m) && al(daug, m) && al(dx, m) && al(wa, 15) && al(wo, 15), "dsrg_igl_blend_bwd: misaligned pointer");
+  if (M == 0) return DSRG_OK;
+  const int rpb = strip(M);
+  dim3 grid((M + rpb - 1) / rpb), block(256);
+  if (dtype == DSRG_F32)
+    hipLaunchKernelGGL((igl_blend_bwd_kernel<float>), grid, block, (size_t)2 * H * 4, (hipStream_t)stream, (const float*)aug, (const float*)x, wa, ba, wo,
+                       bo, (const float*)dout, (float*)daug, (float*)dx, dwa, dwo, dbias, M, H, rpb);
+  else
+    hipLaunchKernelGGL((igl_blend_bwd_kernel<bf16_t>), grid, block, (size_t)2 * H * 4, (hipStream_t)stream, (const bf16_t*)aug, (const bf16_t*)x, wa, ba,
+                       wo, bo, (const bf16_t*)dout, (bf16_t*)daug, (bf16_t*)dx, dwa, dwo, dbias, M, H, rpb);
+  DSRG_LAUNCH_CHECK("dsrg_igl_blend_bwd");
+  return DSRG_OK;
+}

@@ -465,50 +465,105 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
     return _call(hip, aten, base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
 
 
+class _GroupMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, G):
+        ctx.G, ctx.shape = G, x.shape
+        return K.group_mean(x, G)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.group_mean_bwd(dy, ctx.G).view(ctx.shape), None
+
+
 def group_mean(x, G, out=None):
-    return _call(lambda x: K.group_mean(x, G, out),
-                 lambda x: x.float().reshape(-1, G, x.shape[-1]).mean(1).to(x.dtype), x)
+    if _needs_grad((x,)):
+        return _GroupMeanFn.apply(x, G)
+    return K.group_mean(x, G, out)
+
+
+class _GaaPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return K.gaa_pool(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, b = ctx.saved_tensors
+        dx, dw, db = K.gaa_pool_bwd(x, w, b, dout)
+        return dx, dw.view(w.shape), db.view(b.shape)
 
 
 def gaa_pool(x, w, b):
-    def aten(x, w, b):
-        xf = x.float()
-        a = torch.softmax(torch.tanh(xf @ w + b), 1)
-        return (xf * a[..., None]).sum(1).to(x.dtype)
-    return _call(K.gaa_pool, aten, x, w, b)
+    """GAA (vilmodel.py:735-740): softmax_v(tanh(x_v.w + b))-weighted sum over the views; hand-written backward."""
+    if _needs_grad((x, w, b)):
+        return _GaaPoolFn.apply(x if x.is_contiguous() else x.contiguous(), w, b)
+    return K.gaa_pool(x, w, b)
+
+
+class _HeadTailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, gamma, beta, w2, b2, eps):
+        ctx.eps = eps
+        ctx.save_for_backward(h, gamma, beta, w2)
+        ctx.b2_shape = b2.shape
+        return K.head_tail(h, gamma, beta, w2, b2, eps)
+
+    @staticmethod
+    def backward(ctx, dscore):
+        h, gamma, beta, w2 = ctx.saved_tensors
+        dh, dg, dbt, dw2, db2 = K.head_tail_bwd(h, gamma, beta, w2, dscore, ctx.eps)
+        return dh, dg, dbt, dw2.view(w2.shape), db2.view(ctx.b2_shape), None
 
 
 def head_tail(h, gamma, beta, w2, b2, eps=1e-12):
-    def aten(h, g, be, w2, b2):
-        return F.layer_norm(h, (h.shape[-1],), g, be, eps) @ w2 + b2
-    return _call(lambda h, g, be, w2, b2: K.head_tail(h, g, be, w2, b2, eps), aten, h, gamma, beta, w2, b2)
+    """ClsPrediction tail (vilmodel.py:616-628): LayerNorm + Linear(H, 1) on the fp32 hidden rows."""
+    if _needs_grad((h, gamma, beta, w2, b2)):
+        return _HeadTailFn.apply(h, gamma, beta, w2, b2, eps)
+    return K.head_tail(h, gamma, beta, w2, b2, eps)
+
+
+class _NavLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, l, f, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
+        ctx.save_for_backward(g, l, f, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+        ctx.set_materialize_grads(False)
+        return K.nav_logits(g, l, f, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+
+    @staticmethod
+    def backward(ctx, dgl, dll, dfl):
+        g, l, f, gm, gv, vn, src, bw = ctx.saved_tensors
+        dg, dl, df = K.nav_logits_bwd(g, l, f, gm, gv, vn, src, bw, dgl, dll, dfl)
+        return dg, dl, df, None, None, None, None, None
 
 
 def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
-    def hip(g, l, f):
-        return K.nav_logits(g, l, f, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+    """dynamic fusion weight, the three masked_fill_ and the logit-fusion loop (vilmodel.py:773-805) -> global, local, fused."""
+    if _needs_grad((g_raw, l_raw, fuse_raw)):
+        return _NavLogitsFn.apply(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+    return K.nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
 
-    def aten(g, l, f):
-        fw = torch.sigmoid(f)[:, None] if f is not None else 0.5
-        ninf = float('-inf')
-        gl = (g * fw).masked_fill(gmap_visited | ~gmap_masks, ninf)
-        ll = (l * (1 - fw)).masked_fill(~vp_nav_masks, ninf)
-        bw = torch.where(bw_mask.bool(), ll, torch.zeros_like(ll)).sum(1, keepdim=True)
-        src = gmap_src.long()
-        picked = torch.gather(ll, 1, src.clamp(min=0))
-        add = torch.where(src >= 0, picked, torch.where(src == -2, bw.expand_as(picked), torch.zeros_like(picked)))
-        add = torch.cat([ll[:, :1], add[:, 1:]], 1)
-        return gl, ll, gl + add
 
-    return _call(hip, aten, g_raw, l_raw, fuse_raw)
+class _IglBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aug, x, wa, ba, wo, bo):
+        ctx.save_for_backward(aug, x, wa, ba, wo, bo)
+        return K.igl_blend(aug, x, wa, ba, wo, bo)
+
+    @staticmethod
+    def backward(ctx, dout):
+        aug, x, wa, ba, wo, bo = ctx.saved_tensors
+        daug, dx, dwa, dba, dwo, dbo = K.igl_blend_bwd(aug, x, wa, ba, wo, bo, dout)
+        return daug, dx, dwa.view(wa.shape), dba.view(ba.shape), dwo.view(wo.shape), dbo.view(bo.shape)
 
 
 def igl_blend(aug, x, wa, ba, wo, bo):
-    def aten(aug, x, wa, ba, wo, bo):
-        a, xf = aug.float(), x.float()
-        w = torch.sigmoid(a @ wa + ba + xf @ wo + bo)[..., None]
-        return (w * a + (1 - w) * xf).to(x.dtype)
-    return _call(K.igl_blend, aten, aug, x, wa, ba, wo, bo)
+    """IGL gate (vilmodel.py:525-528): w = sigmoid(aug.wa + ba + x.wo + bo); out = w aug + (1 - w) x."""
+    if _needs_grad((aug, x, wa, ba, wo, bo)):
+        c = lambda t: t if t.is_contiguous() else t.contiguous()
+        return _IglBlendFn.apply(c(aug), c(x), wa, ba, wo, bo)
+    return K.igl_blend(aug, x, wa, ba, wo, bo)
 
 
 # ----------------------------------------------------------------------------- action selection + loss tail (agent.py:484-516)

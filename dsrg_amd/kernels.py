@@ -420,3 +420,65 @@ def action_tail(logits, targets=None, u=None, ignore_index=-100, want_grad=False
                                         _p(out['argmax']), _p(out.get('sample')), _p(out['entropy']), _p(out.get('loss_rows')),
                                         _p(out.get('dlogits')), B, N, _stream()), 'dsrg_action_tail_fwd')
     return out
+
+
+# ----------------------------------------------------------------------------- backward of the row kernels
+def group_mean_bwd(dy, G):
+    lib = _lib.load()
+    dy = rows_ok(dy)
+    M, lddy = _rows(dy)
+    H = dy.shape[-1]
+    dx = torch.empty(M * G, H, device=dy.device, dtype=dy.dtype)
+    _lib.check(lib.dsrg_group_mean_bwd(_p(dy), lddy, _p(dx), H, M, G, H, _dt(dy), _stream()), 'dsrg_group_mean_bwd')
+    return dx
+
+
+def gaa_pool_bwd(x, w, b, dout):
+    lib = _lib.load()
+    B, V, H = x.shape
+    dout = dout.to(x.dtype).contiguous()
+    dx = torch.empty_like(x)
+    dwb = torch.zeros(H + 1, device=x.device, dtype=torch.float32)
+    _lib.check(lib.dsrg_gaa_pool_bwd(_p(x), _p(w), _p(b), _p(dout), _p(dx), _p(dwb), dwb.data_ptr() + 4 * H, B, V, H, _dt(x), _stream()),
+               'dsrg_gaa_pool_bwd')
+    return dx, dwb[:H], dwb[H:]
+
+
+def head_tail_bwd(h, gamma, beta, w2, dscore, eps=1e-12):
+    lib = _lib.load()
+    M, ldh = _rows(h)
+    H = h.shape[-1]
+    dscore = dscore.float().contiguous()
+    dh = torch.empty(h.shape, device=h.device, dtype=torch.float32)
+    acc = torch.zeros(3 * H + 1, device=h.device, dtype=torch.float32)
+    base = acc.data_ptr()
+    _lib.check(lib.dsrg_head_tail_bwd(_p(h), ldh, _p(gamma), _p(beta), _p(w2), _p(dscore), float(eps), _p(dh), H, base, base + 4 * H,
+                                      base + 8 * H, base + 12 * H, M, H, _stream()), 'dsrg_head_tail_bwd')
+    return dh, acc[:H], acc[H:2 * H], acc[2 * H:3 * H], acc[3 * H:]
+
+
+def nav_logits_bwd(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask, dgl, dll, dfl):
+    lib = _lib.load()
+    B, G = g_raw.shape
+    Vp = l_raw.shape[1]
+    c = lambda t: None if t is None else t.float().contiguous()
+    dgl, dll, dfl = c(dgl), c(dll), c(dfl)
+    dg, dl = torch.empty_like(g_raw), torch.empty_like(l_raw)
+    df = torch.empty(B, device=g_raw.device, dtype=torch.float32) if fuse_raw is not None else None
+    _lib.check(lib.dsrg_nav_logits_bwd(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gmap_masks), _p(gmap_visited), _p(vp_nav_masks), _p(gmap_src),
+                                       _p(bw_mask), _p(dgl), _p(dll), _p(dfl), _p(dg), _p(dl), _p(df), B, G, Vp, _stream()),
+               'dsrg_nav_logits_bwd')
+    return dg, dl, df
+
+
+def igl_blend_bwd(aug, x, wa, ba, wo, bo, dout):
+    lib = _lib.load()
+    H = x.shape[-1]
+    M = x.numel() // H
+    dout = dout.to(x.dtype).contiguous()
+    daug, dx = torch.empty_like(aug), torch.empty_like(x)
+    acc = torch.zeros(2 * H + 2, device=x.device, dtype=torch.float32)
+    base = acc.data_ptr()
+    _lib.check(lib.dsrg_igl_blend_bwd(_p(aug), _p(x), _p(wa), _p(ba), _p(wo), _p(bo), _p(dout), _p(daug), _p(dx), base, base + 4 * H,
+                                      base + 8 * H, M, H, _dt(x), _stream()), 'dsrg_igl_blend_bwd')
+    return daug, dx, acc[:H], acc[2 * H:2 * H + 1], acc[H:2 * H], acc[2 * H + 1:]

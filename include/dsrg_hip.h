@@ -212,6 +212,27 @@ int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int
                        void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
                        int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream);
 
+/* Backward of the row kernels (each recomputes its forward values; parameter gradients are accumulated with float
+ * atomics into fp32 buffers the caller has zeroed; activation gradients are written in the storage dtype). */
+int dsrg_group_mean_bwd(const void* dy, int lddy, void* dx, int lddx, int M, int G, int H, int dtype, void* stream);
+/* GAA pooling: dx [B,V,H], dw [H], db [1] from dout [B,H] (all of x / dout / dx contiguous). */
+int dsrg_gaa_pool_bwd(const void* x, const float* w, const float* bias, const void* dout, void* dx, float* dw, float* db,
+                      int B, int V, int H, int dtype, void* stream);
+/* ClsPrediction tail: dh [M,H] fp32, dgamma / dbeta / dw2 [H], db2 [1] from dscore [M]. */
+int dsrg_head_tail_bwd(const float* h, int ldh, const float* gamma, const float* beta, const float* w2, const float* dscore,
+                       float eps, float* dh, int lddh, float* dgamma, float* dbeta, float* dw2, float* db2, int M, int H,
+                       void* stream);
+/* Dynamic fusion + logit fusion: gradients of the three raw score inputs from the gradients of the three logit outputs
+ * (any of dglobal / dlocal / dfused may be NULL = zero); masked (-inf) positions pass no gradient, like masked_fill_. */
+int dsrg_nav_logits_bwd(const float* g_raw, const float* l_raw, const float* fuse_raw, const uint8_t* gmap_masks,
+                        const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const int32_t* gmap_src,
+                        const uint8_t* bw_mask, const float* dglobal, const float* dlocal, const float* dfused,
+                        float* dg_raw, float* dl_raw, float* dfuse_raw, int B, int G, int Vp, void* stream);
+/* IGL gate: daug / dx [M,H], dwa / dwo [H], dbias[2] = (dba, dbo). */
+int dsrg_igl_blend_bwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo, const float* bo,
+                       const void* dout, void* daug, void* dx, float* dwa, float* dwo, float* dbias, int M, int H, int dtype,
+                       void* stream);
+
 /* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
  *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].
  * x is `in_dtype` (fp32 pre-LN sums or `dtype`), residual / dy / dz are `dtype`. */
