@@ -30,6 +30,14 @@ class AttnProblem(C.Structure):
 ATTN_MAX_GROUPS = 4
 
 
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('base', 'feat', 'Wf', 'bf', 'lnf_gamma', 'lnf_beta', 'E1', 'idx1', 'E2', 'idx2', 'vec',
+                                          'lno_gamma', 'lno_beta', 'dout', 'dbase', 'dWf', 'dbf', 'dlnf_gamma', 'dlnf_beta', 'dE1',
+                                          'dE2', 'dvec', 'dlno_gamma', 'dlno_beta')] + \
+               [(n, C.c_int32) for n in ('ldb', 'ldf', 'F', 'idx1_kind', 'idx1_stride', 'idx1_div', 'idx2_kind', 'idx2_stride',
+                                         'idx2_div', 'lddo', 'lddb', 'M', 'H', 'dtype')] + [('eps', C.c_float)]
+
+
 class LnProblem(C.Structure):
     _fields_ = [('x', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('out', C.c_void_p),
                 ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32)]
@@ -64,6 +72,7 @@ SIGNATURES = {
     'dsrg_head_tail_bwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_nav_logits_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_igl_blend_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_embed_ln_bwd': (C.c_int, [C.POINTER(EmbedBwdArgs), _P]),
     'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }

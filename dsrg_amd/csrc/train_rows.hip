@@ -280,6 +280,123 @@ __global__ __launch_bounds__(256) void igl_blend_bwd_kernel(const T* __restrict_
   if (lane == 0 && sds != 0.f) { atomicAdd(dbias, sds); atomicAdd(dbias + 1, sds); }
 }
 
+// ---- token-embedding sums backward (forward: embed_ln_kernel, rowops.hip)
+//   out = LNo( base + LNf(Wf.feat + bf) + E1[i1] + E2[i2] + vec )     (every term optional)
+// One wave per row, a strip of rows per workgroup.  Column-vector gradients and dWf are summed in LDS (ds_add_f32) and
+// leave with one global atomic per element per workgroup; table rows get their dz by global atomics (dense fp32 tables).
+__device__ __forceinline__ int embed_index_b(const void* p, int kind, int stride, int div, int row) {
+  const size_t o = (size_t)(row / div) * stride;
+  if (kind == DSRG_IDX_I32) return reinterpret_cast<const int32_t*>(p)[o];
+  if (kind == DSRG_IDX_I64) return (int)reinterpret_cast<const int64_t*>(p)[o];
+  return (int)reinterpret_cast<const float*>(p)[o];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_args_t a, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H, F = a.F, nv = (H + 255) / 256, HS = H + 4;
+  float* WT = lds;                                   // [F][HS] forward weight, transposed
+  float* dWT = WT + (a.feat ? F * HS : 0);           // [F][HS] its gradient
+  float* col = dWT + (a.feat ? F * HS : 0);          // [6][H]: dbf, dlnf_g, dlnf_b, dvec, dlno_g, dlno_b
+  if (a.feat)
+    for (int j = threadIdx.x; j < H * F; j += 256) {
+      const int h = j / F, k = j - h * F;
+      WT[k * HS + h] = a.Wf[j];
+      dWT[k * HS + h] = 0.f;
+    }
+  for (int j = threadIdx.x; j < 6 * H; j += 256) col[j] = 0.f;
+  __syncthreads();
+  const T* base = reinterpret_cast<const T*>(a.base);
+  const T* dout = reinterpret_cast<const T*>(a.dout);
+  T* dbase = reinterpret_cast<T*>(a.dbase);
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(a.M, m0 + rows_per_block);
+  for (int row = m0 + wave; row < m1; row += WPB) {
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = (a.feat && k < F) ? a.feat[(size_t)row * a.ldf + k] : 0.f;
+    const int i1 = a.E1 ? embed_index_b(a.idx1, a.idx1_kind, a.idx1_stride, a.idx1_div, row) : 0;
+    const int i2 = a.E2 ? embed_index_b(a.idx2, a.idx2_kind, a.idx2_stride, a.idx2_div, row) : 0;
+    float4 zf[MAXV], z[MAXV], g[MAXV];
+    float rstd_f = 1.f, rstd_o = 1.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) zf[i] = z[i] = g[i] = f4(0.f);
+    if (a.feat) {
+#pragma unroll
+      ROWV(i, c) {
+        float4 o = a.bf ? *reinterpret_cast<const float4*>(a.bf + c) : f4(0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < F) o = o + f[k] * *reinterpret_cast<const float4*>(&WT[k * HS + c]);
+        zf[i] = o;
+      } ENDV
+      if (a.lnf_gamma) {
+        rstd_f = ln_hat(zf, nv, lane, H, a.eps);
+#pragma unroll
+        ROWV(i, c) z[i] = zf[i] * *reinterpret_cast<const float4*>(a.lnf_gamma + c) + *reinterpret_cast<const float4*>(a.lnf_beta + c); ENDV
+      } else {
+#pragma unroll
+        ROWV(i, c) z[i] = zf[i]; ENDV
+      }
+    }
+#pragma unroll
+    ROWV(i, c) {
+      if (base) z[i] = z[i] + ld4(base + (size_t)row * a.ldb + c);
+      if (a.E1) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c);
+      if (a.E2) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c);
+      if (a.vec) z[i] = z[i] + *reinterpret_cast<const float4*>(a.vec + c);
+      g[i] = ld4(dout + (size_t)row * a.lddo + c);
+    } ENDV
+    if (a.lno_gamma) {
+      rstd_o = ln_hat(z, nv, lane, H, a.eps);            // z <- normalised row
+#pragma unroll
+      ROWV(i, c) {
+        lds_add4(col + 4 * H + c, g[i] * z[i]);
+        lds_add4(col + 5 * H + c, g[i]);
+        g[i] = g[i] * *reinterpret_cast<const float4*>(a.lno_gamma + c);
+      } ENDV
+      ln_dz(g, z, rstd_o, nv, lane, H);
+    }
+    // g = dz: gradient of the pre-LayerNorm sum
+#pragma unroll
+    ROWV(i, c) {
+      if (dbase) st4(dbase + (size_t)row * a.lddb + c, g[i]);
+      if (a.dE1) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics (generic atomicAdd)
+      if (a.dE2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
+      if (a.vec) lds_add4(col + 3 * H + c, g[i]);
+    } ENDV
+    if (a.feat) {
+      if (a.lnf_gamma) {
+#pragma unroll
+        ROWV(i, c) {
+          lds_add4(col + 1 * H + c, g[i] * zf[i]);
+          lds_add4(col + 2 * H + c, g[i]);
+          g[i] = g[i] * *reinterpret_cast<const float4*>(a.lnf_gamma + c);
+        } ENDV
+        ln_dz(g, zf, rstd_f, nv, lane, H);
+      }
+#pragma unroll
+      ROWV(i, c) {
+        lds_add4(col + c, g[i]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < F) lds_add4(&dWT[k * HS + c], f[k] * g[i]);
+      } ENDV
+    }
+  }
+  __syncthreads();
+  if (a.feat) {
+    for (int j = threadIdx.x; j < H * F; j += 256) {
+      const int h = j / F, k = j - h * F;
+      atomicAdd(a.dWf + j, dWT[k * HS + h]);
+    }
+    if (a.dbf) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dbf + c, col[c]);
+    if (a.lnf_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlnf_gamma + c, col[H + c]); atomicAdd(a.dlnf_beta + c, col[2 * H + c]); }
+  }
+  if (a.vec) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dvec + c, col[3 * H + c]);
+  if (a.lno_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlno_gamma + c, col[4 * H + c]); atomicAdd(a.dlno_beta + c, col[5 * H + c]); }
+}
+
 inline bool okdt(int d) { return d == DSRG_F32 || d == DSRG_BF16; }
 inline bool al(const void* p, uintptr_t m) { return ((uintptr_t)p & m) == 0; }
 inline int strip(int M) { int r = (M + 511) / 512; return r < WPB ? WPB : (r + WPB - 1) / WPB * WPB; }   // <= ~512 workgroups
@@ -360,5 +477,38 @@ extern "C" int dsrg_igl_blend_bwd(const void* aug, const void* x, const float* w
     hipLaunchKernelGGL((igl_blend_bwd_kernel<bf16_t>), grid, block, (size_t)2 * H * 4, (hipStream_t)stream, (const bf16_t*)aug, (const bf16_t*)x, wa, ba,
                        wo, bo, (const bf16_t*)dout, (bf16_t*)daug, (bf16_t*)dx, dwa, dwo, dbias, M, H, rpb);
   DSRG_LAUNCH_CHECK("dsrg_igl_blend_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream) {
+  DSRG_CHECK(args, "dsrg_embed_ln_bwd: null args");
+  const dsrg_embed_bwd_args_t& a = *args;
+  DSRG_CHECK(okdt(a.dtype) && a.dout && a.M >= 0, "dsrg_embed_ln_bwd: bad dtype or null dout");
+  DSRG_CHECK(a.H > 0 && a.H <= 1024 && a.H % 64 == 0, "dsrg_embed_ln_bwd: H=%d must be a multiple of 64 and <= 1024", a.H);
+  DSRG_CHECK(!a.feat || (a.Wf && a.dWf && a.F >= 1 && a.F <= 16 && a.ldf >= a.F && (!a.bf == !a.dbf)), "dsrg_embed_ln_bwd: feature term needs Wf, dWf, 1 <= F <= 16");
+  DSRG_CHECK((!a.lnf_gamma || (a.feat && a.lnf_beta && a.dlnf_gamma && a.dlnf_beta)) && (!a.lno_gamma || (a.lno_beta && a.dlno_gamma && a.dlno_beta)),
+             "dsrg_embed_ln_bwd: LayerNorm operands / gradients incomplete");
+  DSRG_CHECK((!a.E1 || a.idx1) && (!a.E2 || a.idx2) && (!a.dE1 || a.E1) && (!a.dE2 || a.E2) && (!a.vec == !a.dvec), "dsrg_embed_ln_bwd: table / index / gradient mismatch");
+  DSRG_CHECK((!a.E1 || (a.idx1_kind >= DSRG_IDX_I32 && a.idx1_kind <= DSRG_IDX_F32 && a.idx1_stride >= 1 && a.idx1_div >= 1)) &&
+                 (!a.E2 || (a.idx2_kind >= DSRG_IDX_I32 && a.idx2_kind <= DSRG_IDX_F32 && a.idx2_stride >= 1 && a.idx2_div >= 1)),
+             "dsrg_embed_ln_bwd: bad index kind / stride / div");
+  DSRG_CHECK(a.lddo >= a.H && a.lddo % 4 == 0 && (!a.base || (a.ldb >= a.H && a.ldb % 4 == 0)) && (!a.dbase || (a.lddb >= a.H && a.lddb % 4 == 0)),
+             "dsrg_embed_ln_bwd: bad leading dims");
+  const uintptr_t m = a.dtype == DSRG_BF16 ? 7 : 15;
+  DSRG_CHECK(al(a.dout, m) && al(a.base, m) && al(a.dbase, m) && al(a.E1, 15) && al(a.E2, 15) && al(a.vec, 15) && al(a.bf, 15) && al(a.lnf_gamma, 15) &&
+                 al(a.lnf_beta, 15) && al(a.lno_gamma, 15) && al(a.lno_beta, 15), "dsrg_embed_ln_bwd: misaligned pointer");
+  if (a.M == 0) return DSRG_OK;
+  const int rpb = strip(a.M);
+  const size_t lds = ((a.feat ? 2 * (size_t)a.F * (a.H + 4) : 0) + 6 * (size_t)a.H) * sizeof(float);    // <= 156 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid((a.M + rpb - 1) / rpb), block(256);
+  if (a.dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), grid, block, lds, (hipStream_t)stream, a, rpb);
+  else hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, rpb);
+  DSRG_LAUNCH_CHECK("dsrg_embed_ln_bwd");
   return DSRG_OK;
 }

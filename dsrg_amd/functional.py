@@ -1,67 +1,19 @@
 """Differentiable ops of the DSRG hot path.
 
-Forward ALWAYS runs the hand-written HIP kernel (kernels.py -> libdsrg_hip.so); there is no other forward.
-Backward:
-  * linear / grouped linear, dense(+dropout)+residual+LayerNorm, LayerNorm, activations: hand-written HIP
-    (dgrad / wgrad on the MFMA GEMM with transposed operands, LayerNorm-backward and activation-backward kernels,
-    bias column sums) -- >= 97 % of the backward FLOPs;
+Forward ALWAYS runs the hand-written HIP kernel (kernels.py -> libdsrg_hip.so); there is no other forward, and every
+backward is a hand-written HIP kernel as well:
+  * linear / grouped linear, dense(+dropout)+residual+LayerNorm, LayerNorm, activations: dgrad / wgrad on the MFMA GEMM
+    with transposed operands, LayerNorm-backward and activation-backward kernels, bias column sums fused into the dY
+    transpose -- >= 97 % of the backward FLOPs;
   * attention: two recompute kernels (dQ; dK/dV) from the forward's log-sum-exp, fp32 arithmetic;
-  * token-embedding sums, GAA pooling, head tails, logit fusion, IGL gate: `_Fused` -- the backward
-    re-expresses the op with ATen ops on the saved inputs and differentiates that (small ops; next to be replaced).
-"""
+  * token-embedding sums, GAA pooling, ASV mean, head tails, logit fusion, IGL gate: train_rows.hip.
+ATen is used for bookkeeping only (dropout masks, views, zero-filled gradient buffers)."""
 import math
 import torch
 import torch.nn.functional as F
 
 from . import _lib, kernels as K
 from ._lib import ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1
-
-
-class _Fused(torch.autograd.Function):
-    """forward = hip_fn(*args); backward = autograd through aten_fn(*args) recomputed on saved inputs."""
-
-    @staticmethod
-    def forward(ctx, hip_fn, aten_fn, *args):
-        ctx.aten_fn = aten_fn
-        ctx.is_t = [isinstance(a, torch.Tensor) for a in args]
-        ctx.consts = [None if t else a for a, t in zip(args, ctx.is_t)]
-        ctx.save_for_backward(*[a for a in args if isinstance(a, torch.Tensor)])
-        ctx.req = [isinstance(a, torch.Tensor) and a.requires_grad for a in args]
-        with torch.no_grad():
-            out = hip_fn(*args)
-        ctx.multi = isinstance(out, (tuple, list))
-        return tuple(out) if ctx.multi else out
-
-    @staticmethod
-    def backward(ctx, *grads):
-        saved = list(ctx.saved_tensors)
-        args, leaves = [], []
-        for is_t, c, r in zip(ctx.is_t, ctx.consts, ctx.req):
-            if is_t:
-                t = saved.pop(0).detach()
-                if r:
-                    t.requires_grad_(True)
-                    leaves.append(t)
-                args.append(t)
-            else:
-                args.append(c)
-        with torch.enable_grad():
-            outs = ctx.aten_fn(*args)
-            outs = list(outs) if ctx.multi else [outs]
-            pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
-            gin = torch.autograd.grad([o for o, _ in pairs], leaves, [g.to(o.dtype) for o, g in pairs],
-                                      allow_unused=True) if pairs and leaves else [None] * len(leaves)
-        gin = list(gin)
-        res = [None, None]
-        for r in ctx.req:
-            res.append(gin.pop(0) if r else None)
-        return tuple(res)
-
-
-def _call(hip_fn, aten_fn, *args):
-    if torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in args):
-        return _Fused.apply(hip_fn, aten_fn, *args)
-    return hip_fn(*args)
 
 
 # ----------------------------------------------------------------------------- weight packing
@@ -429,40 +381,42 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
 
 
 # ----------------------------------------------------------------------------- token embedding
-def _rows_index(idx, M):
-    """embed_ln index operand (tensor or (tensor, div)) -> int64 [M]"""
-    t, div = idx if isinstance(idx, tuple) else (idx, 1)
-    t = t.long()
-    return t if div == 1 else t.repeat_interleave(div)[:M]
+class _EmbedLnFn(torch.autograd.Function):
+    """out = LNo(base + LNf(Wf.feat + bf) + E1[i1] + E2[i2] + vec); backward = dsrg_embed_ln_bwd (one kernel)."""
+
+    @staticmethod
+    def forward(ctx, cfg, base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b):
+        M, H, dtype, device, idx1, idx2, eps = cfg
+        ctx.cfg = cfg
+        ctx.save_for_backward(base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
+        return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, (lnf_g, lnf_b) if lnf_g is not None else None,
+                          E1, idx1, E2, idx2, vec, (lno_g, lno_b) if lno_g is not None else None, eps)
+
+    @staticmethod
+    def backward(ctx, dout):
+        M, H, dtype, device, idx1, idx2, eps = ctx.cfg
+        base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b = ctx.saved_tensors
+        if feat is not None and ctx.needs_input_grad[2]:
+            raise _lib.DsrgHipError('embed_ln: no gradient w.r.t. the raw feature input')
+        g = K.embed_ln_bwd(M, H, dout.to(dtype), base, feat, Wf, bf, (lnf_g, lnf_b) if lnf_g is not None else None, E1, idx1, E2, idx2,
+                           vec, (lno_g, lno_b) if lno_g is not None else None, eps, need_dbase=ctx.needs_input_grad[1])
+        db = g['base']
+        if db is not None and base is not None:
+            db = db.view(base.shape)
+        return (None, db, None, g['Wf'], g['bf'], g['lnf_g'], g['lnf_b'], g['E1'], g['E2'], g['vec'], g['lno_g'], g['lno_b'])
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
              E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
+    """Token-embedding sum + LayerNorm(s) (BertEmbeddings and the four visual token sites, see include/dsrg_hip.h)."""
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
-
-    def hip(base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b):
-        return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, (lnf_g, lnf_b) if lnf_g is not None else None,
-                          E1, idx1, E2, idx2, vec, (lno_g, lno_b) if lno_g is not None else None, eps, out)
-
-    def aten(base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b):
-        z = torch.zeros(M, H, device=device)
-        if feat is not None:
-            t = F.linear(feat.reshape(M, -1), Wf, bf)
-            z = F.layer_norm(t, (H,), lnf_g, lnf_b, eps) if lnf_g is not None else t
-        if base is not None:
-            z = z + base.reshape(M, H).float()
-        if E1 is not None:
-            z = z + F.embedding(_rows_index(idx1, M), E1)      # embedding_dense_backward, not the slow index_put path
-        if E2 is not None:
-            z = z + F.embedding(_rows_index(idx2, M), E2)
-        if vec is not None:
-            z = z + vec
-        if lno_g is not None:
-            z = F.layer_norm(z, (H,), lno_g, lno_b, eps)
-        return z.to(dtype)
-
-    return _call(hip, aten, base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
+    ts = (base, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
+    if _needs_grad(ts):
+        if base is not None and base.dim() != 2:
+            base = base.reshape(M, H)
+        return _EmbedLnFn.apply((M, H, dtype, device, idx1, idx2, eps), base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
+    return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out)
 
 
 class _GroupMeanFn(torch.autograd.Function):

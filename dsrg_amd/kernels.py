@@ -482,3 +482,31 @@ def igl_blend_bwd(aug, x, wa, ba, wo, bo, dout):
     _lib.check(lib.dsrg_igl_blend_bwd(_p(aug), _p(x), _p(wa), _p(ba), _p(wo), _p(bo), _p(dout), _p(daug), _p(dx), base, base + 4 * H,
                                       base + 8 * H, M, H, _dt(x), _stream()), 'dsrg_igl_blend_bwd')
     return daug, dx, acc[:H], acc[2 * H:2 * H + 1], acc[H:2 * H], acc[2 * H + 1:]
+
+
+def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None, E2=None, idx2=None,
+                 vec=None, lno=None, eps=1e-12, need_dbase=True):
+    """Backward of embed_ln -> dict with the gradients of the terms that are present (fp32, table gradients dense)."""
+    lib = _lib.load()
+    dout = rows_ok(dout)
+    _dev(dout)
+    dev = dout.device
+    a = _lib.EmbedBwdArgs()
+    lnf_g, lnf_b = lnf if lnf is not None else (None, None)
+    lno_g, lno_b = lno if lno is not None else (None, None)
+    i1, k1, s1, d1 = _idx(idx1 if E1 is not None else None, M, 'idx1')
+    i2, k2, s2, d2 = _idx(idx2 if E2 is not None else None, M, 'idx2')
+    z = lambda t: None if t is None else torch.zeros_like(t, dtype=torch.float32)
+    g = {'Wf': z(Wf) if feat is not None else None, 'bf': z(bf) if feat is not None else None,
+         'lnf_g': z(lnf_g), 'lnf_b': z(lnf_b), 'E1': z(E1), 'E2': z(E2), 'vec': z(vec), 'lno_g': z(lno_g), 'lno_b': z(lno_b),
+         'base': torch.empty(M, H, device=dev, dtype=dout.dtype) if (base is not None and need_dbase) else None}
+    a.base, a.feat, a.Wf, a.bf, a.lnf_gamma, a.lnf_beta = _p(base), _p(feat), _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b)
+    a.E1, a.idx1, a.E2, a.idx2, a.vec, a.lno_gamma, a.lno_beta, a.dout = _p(E1), _p(i1), _p(E2), _p(i2), _p(vec), _p(lno_g), _p(lno_b), _p(dout)
+    a.dbase, a.dWf, a.dbf, a.dlnf_gamma, a.dlnf_beta = _p(g['base']), _p(g['Wf']), _p(g['bf']), _p(g['lnf_g']), _p(g['lnf_b'])
+    a.dE1, a.dE2, a.dvec, a.dlno_gamma, a.dlno_beta = _p(g['E1']), _p(g['E2']), _p(g['vec']), _p(g['lno_g']), _p(g['lno_b'])
+    a.ldb = _rows(base)[1] if base is not None else 0
+    a.ldf, a.F = (_rows(feat)[1], feat.shape[-1]) if feat is not None else (0, 0)
+    a.idx1_kind, a.idx1_stride, a.idx1_div, a.idx2_kind, a.idx2_stride, a.idx2_div = k1, s1, d1, k2, s2, d2
+    a.lddo, a.lddb, a.M, a.H, a.dtype, a.eps = _rows(dout)[1], H, M, H, _dt(dout), float(eps)
+    _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
+    return g

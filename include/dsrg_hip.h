@@ -233,6 +233,20 @@ int dsrg_igl_blend_bwd(const void* aug, const void* x, const float* wa, const fl
                        const void* dout, void* daug, void* dx, float* dwa, float* dwo, float* dbias, int M, int H, int dtype,
                        void* stream);
 
+/* Token-embedding sums backward (forward operands as dsrg_embed_ln_fwd).  Gradient pointers may be NULL where the
+ * forward term is absent; all of them are fp32 buffers the caller has zeroed (accumulated with float atomics), except
+ * dbase ([M,H], storage dtype, written).  dE1 / dE2 are dense tables like the forward ones. */
+typedef struct {
+  const void* base; const float* feat; const float* Wf; const float* bf; const float* lnf_gamma; const float* lnf_beta;
+  const float* E1; const void* idx1; const float* E2; const void* idx2; const float* vec;
+  const float* lno_gamma; const float* lno_beta; const void* dout;
+  void* dbase; float* dWf; float* dbf; float* dlnf_gamma; float* dlnf_beta; float* dE1; float* dE2; float* dvec;
+  float* dlno_gamma; float* dlno_beta;
+  int32_t ldb, ldf, F, idx1_kind, idx1_stride, idx1_div, idx2_kind, idx2_stride, idx2_div, lddo, lddb, M, H, dtype;
+  float eps;
+} dsrg_embed_bwd_args_t;
+int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
+
 /* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
  *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].
  * x is `in_dtype` (fp32 pre-LN sums or `dtype`), residual / dy / dz are `dtype`. */
