@@ -83,12 +83,14 @@ def bf16_compress_hook(process_group, bucket):
     return fut.then(decompress)
 
 
-def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_graph=False):
+def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_graph=False, force=False):
     """DDP with the reference's semantics.  Larger buckets than torch's 25 MB default: xGMI links are point to point
     (~153 GB/s each), so fewer, larger all-reduces amortise the per-collective latency."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):      # force: wrap even a single rank (tests)
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
+    from . import functional as _Fn
+    _Fn.MATERIALIZE_UNUSED_GRADS = True        # see functional._PackFn
     ids = [device.index] if (device is not None and device.type == 'cuda') else None
     ddp = DDP(model, device_ids=ids, find_unused_parameters=not static_graph, static_graph=static_graph,
               bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)

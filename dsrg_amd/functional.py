@@ -28,6 +28,13 @@ def _foreach_copy_grouped(dsts, srcs):
         torch._foreach_copy_(d, s_)
 
 
+# DistributedDataParallel (find_unused_parameters=True) expects a gradient for every parameter that is REACHABLE in the
+# autograd graph; all parameters reach the single _PackFn node, so under DDP the ones a task did not touch must get an
+# explicit zero gradient (views of one zero buffer: one fill kernel) or the reducer never finishes its buckets.
+# dsrg_amd.distributed.wrap_model switches this on.
+MATERIALIZE_UNUSED_GRADS = False
+
+
 class _PackFn(torch.autograd.Function):
     """All compute-dtype / packed copies of the parameters in one autograd node: forward = one multi-tensor copy
     (torch._foreach_copy_, casts included) of every source into its row range of its packed buffer; backward = one
@@ -68,6 +75,18 @@ class _PackFn(torch.autograd.Function):
                 r += shape[0]
         if dst:
             _foreach_copy_grouped(dst, src)
+        if MATERIALIZE_UNUSED_GRADS:
+            miss = [i for i in range(len(grads)) if grads[i] is None and ctx.needs_input_grad[1 + i]]
+            if miss:
+                by = {}
+                for i in miss:
+                    by.setdefault((ctx.meta[i][1], ctx.meta[i][2]), []).append(i)
+                for (dt, dev), idxs in by.items():
+                    sizes = [int(torch.Size(ctx.meta[i][0]).numel()) for i in idxs]
+                    zero = torch.zeros(sum(sizes), dtype=dt, device=dev)
+                    o = 0
+                    for i, n in zip(idxs, sizes):
+                        grads[i] = zero[o:o + n].view(ctx.meta[i][0]); o += n
         return (None,) + tuple(grads)
 
 

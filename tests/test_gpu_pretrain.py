@@ -59,3 +59,36 @@ def test_pretrain_losses_and_grads(dtype):
                 assert (np.isfinite(t) == fin).all() and np.abs(t[fin] - gg[fin]).max() <= tol
     with pytest.raises(ValueError):
         m(b, 'bogus')
+
+
+def test_ddp_wrapper_with_task_dependent_parameters():
+    """DistributedDataParallel(find_unused_parameters=True) around the HIP pre-training model, one rank on RCCL: every
+    task leaves a different set of heads untouched, and all parameters hang off ONE autograd node (the weight pack), so
+    the reducer must still see a gradient for each of them every step (dsrg_amd.functional.MATERIALIZE_UNUSED_GRADS)."""
+    import torch.distributed as dist
+    from dsrg_amd import distributed as D, functional as Fn
+    gold = common.load_gold('r2r_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        m = _model(torch.bfloat16)
+        ddp = D.wrap_model(m, torch.device('cuda', 0), bf16_grads=True, force=True)
+        assert Fn.MATERIALIZE_UNUSED_GRADS and ddp is not m
+        opt = torch.optim.SGD(m.parameters(), lr=1e-4)
+        for it in range(2):
+            for task in ('mlm', 'mrc', 'sap'):
+                b = common.to_t(synth.pretrain_batch(B, L, O, seed, task), 'cuda')
+                opt.zero_grad(set_to_none=True)
+                loss = ddp(b, task, compute_loss=True).mean()
+                loss.backward()
+                opt.step()
+                assert torch.isfinite(loss)
+        # the last step was 'sap': the MLM head took no part in it, yet it got its (zero) gradient, so its bucket reduced
+        g = dict(m.named_parameters())['mlm_head.predictions.transform.dense.weight'].grad
+        assert g is not None and float(g.abs().max()) == 0.0
+    finally:
+        Fn.MATERIALIZE_UNUSED_GRADS = False
+        if own:
+            dist.destroy_process_group()
