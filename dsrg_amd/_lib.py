@@ -35,7 +35,8 @@ class EmbedBwdArgs(C.Structure):
                                           'lno_gamma', 'lno_beta', 'dout', 'dbase', 'dWf', 'dbf', 'dlnf_gamma', 'dlnf_beta', 'dE1',
                                           'dE2', 'dvec', 'dlno_gamma', 'dlno_beta')] + \
                [(n, C.c_int32) for n in ('ldb', 'ldf', 'F', 'idx1_kind', 'idx1_stride', 'idx1_div', 'idx2_kind', 'idx2_stride',
-                                         'idx2_div', 'lddo', 'lddb', 'M', 'H', 'dtype')] + [('eps', C.c_float)]
+                                         'idx2_div', 'lddo', 'lddb', 'M', 'H', 'dtype')] + [('eps', C.c_float), ('E1_rows', C.c_int32),
+                                                                                   ('E2_rows', C.c_int32)]
 
 
 class LnProblem(C.Structure):

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void igl_blend_bwd_kernel(const T* __restrict_
 //   out = LNo( base + LNf(Wf.feat + bf) + E1[i1] + E2[i2] + vec )     (every term optional)
 // One wave per row, a strip of rows per workgroup.  Column-vector gradients and dWf are summed in LDS (ds_add_f32) and
 // leave with one global atomic per element per workgroup; table rows get their dz by global atomics (dense fp32 tables).
+constexpr int EMB_SMALL = 4;
 __device__ __forceinline__ int embed_index_b(const void* p, int kind, int stride, int div, int row) {
   const size_t o = (size_t)(row / div) * stride;
   if (kind == DSRG_IDX_I32) return reinterpret_cast<const int32_t*>(p)[o];
@@ -299,13 +300,18 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
   float* WT = lds;                                   // [F][HS] forward weight, transposed
   float* dWT = WT + (a.feat ? F * HS : 0);           // [F][HS] its gradient
   float* col = dWT + (a.feat ? F * HS : 0);          // [6][H]: dbf, dlnf_g, dlnf_b, dvec, dlno_g, dlno_b
+  // tables with a handful of rows (nav / token types) would take thousands of global atomics on the same few rows:
+  // their gradient is summed in LDS and leaves once per workgroup
+  const bool small1 = a.dE1 && a.E1_rows <= EMB_SMALL, small2 = a.dE2 && a.E2_rows <= EMB_SMALL;
+  float* tab1 = col + 6 * H;                         // [EMB_SMALL][H]
+  float* tab2 = tab1 + (small1 ? EMB_SMALL * H : 0);
   if (a.feat)
     for (int j = threadIdx.x; j < H * F; j += 256) {
       const int h = j / F, k = j - h * F;
       WT[k * HS + h] = a.Wf[j];
       dWT[k * HS + h] = 0.f;
     }
-  for (int j = threadIdx.x; j < 6 * H; j += 256) col[j] = 0.f;
+  for (int j = threadIdx.x; j < (6 + (small1 ? EMB_SMALL : 0) + (small2 ? EMB_SMALL : 0)) * H; j += 256) col[j] = 0.f;
   __syncthreads();
   const T* base = reinterpret_cast<const T*>(a.base);
   const T* dout = reinterpret_cast<const T*>(a.dout);
@@ -361,8 +367,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
 #pragma unroll
     ROWV(i, c) {
       if (dbase) st4(dbase + (size_t)row * a.lddb + c, g[i]);
-      if (a.dE1) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics (generic atomicAdd)
-      if (a.dE2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
+      if (small1) lds_add4(tab1 + i1 * H + c, g[i]);
+      else if (a.dE1) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics (generic atomicAdd)
+      if (small2) lds_add4(tab2 + i2 * H + c, g[i]);
+      else if (a.dE2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
       if (a.vec) lds_add4(col + 3 * H + c, g[i]);
     } ENDV
     if (a.feat) {
@@ -393,6 +401,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
     if (a.dbf) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dbf + c, col[c]);
     if (a.lnf_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlnf_gamma + c, col[H + c]); atomicAdd(a.dlnf_beta + c, col[2 * H + c]); }
   }
+  if (small1) for (int c = threadIdx.x; c < a.E1_rows * H; c += 256) atomicAdd(a.dE1 + c, tab1[c]);
+  if (small2) for (int c = threadIdx.x; c < a.E2_rows * H; c += 256) atomicAdd(a.dE2 + c, tab2[c]);
   if (a.vec) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dvec + c, col[3 * H + c]);
   if (a.lno_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlno_gamma + c, col[4 * H + c]); atomicAdd(a.dlno_beta + c, col[5 * H + c]); }
 }
@@ -499,7 +509,10 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
                  al(a.lnf_beta, 15) && al(a.lno_gamma, 15) && al(a.lno_beta, 15), "dsrg_embed_ln_bwd: misaligned pointer");
   if (a.M == 0) return DSRG_OK;
   const int rpb = strip(a.M);
-  const size_t lds = ((a.feat ? 2 * (size_t)a.F * (a.H + 4) : 0) + 6 * (size_t)a.H) * sizeof(float);    // <= 156 KiB
+  DSRG_CHECK((!a.dE1 || a.E1_rows >= 1) && (!a.dE2 || a.E2_rows >= 1), "dsrg_embed_ln_bwd: table row counts missing");
+  const int nsmall = ((a.dE1 && a.E1_rows <= EMB_SMALL) ? EMB_SMALL : 0) + ((a.dE2 && a.E2_rows <= EMB_SMALL) ? EMB_SMALL : 0);
+  const size_t lds = ((a.feat ? 2 * (size_t)a.F * (a.H + 4) : 0) + (6 + nsmall) * (size_t)a.H) * sizeof(float);
+  DSRG_CHECK(lds <= 160 * 1024, "dsrg_embed_ln_bwd: F=%d, H=%d with small tables needs %zu B of LDS", a.F, a.H, lds);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

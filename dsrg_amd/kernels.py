@@ -508,5 +508,6 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
     a.ldf, a.F = (_rows(feat)[1], feat.shape[-1]) if feat is not None else (0, 0)
     a.idx1_kind, a.idx1_stride, a.idx1_div, a.idx2_kind, a.idx2_stride, a.idx2_div = k1, s1, d1, k2, s2, d2
     a.lddo, a.lddb, a.M, a.H, a.dtype, a.eps = _rows(dout)[1], H, M, H, _dt(dout), float(eps)
+    a.E1_rows, a.E2_rows = (E1.shape[0] if E1 is not None else 0), (E2.shape[0] if E2 is not None else 0)
     _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
     return g

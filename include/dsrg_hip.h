@@ -244,6 +244,7 @@ typedef struct {
   float* dlno_gamma; float* dlno_beta;
   int32_t ldb, ldf, F, idx1_kind, idx1_stride, idx1_div, idx2_kind, idx2_stride, idx2_div, lddo, lddb, M, H, dtype;
   float eps;
+  int32_t E1_rows, E2_rows;   /* rows of the tables (tables of <= 4 rows are summed in LDS first) */
 } dsrg_embed_bwd_args_t;
 int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
 
