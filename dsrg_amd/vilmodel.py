@@ -171,6 +171,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self.init_weights()
         self._apply_freeze_flags()
         self._wcache, self._kv_cache = None, None
+        self._side_stream, self.overlap_streams = None, True
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
     # ---------------------------------------------------------------- construction helpers
@@ -441,16 +442,42 @@ class GlocalTextPathNavCMT(nn.Module):
         a_fn(cat[..., :ha]); b_fn(cat[..., ha:])
         return cat
 
+    # ---------------------------------------------------------------- independent sub-graphs on a second HIP stream
+    def _fork(self, fn):
+        """Run fn() on the model's side stream (no-grad mode only) and return join() -> its result.  The object-token
+        encoder and the view encoder of a panorama, or the SAP heads and the RMF poolers of a navigation step, are
+        independent chains of small launches that each leave most of the 256 CUs idle; on two streams (two branches of
+        the captured HIP graph) they run side by side."""
+        if torch.is_grad_enabled() or not self.overlap_streams:
+            r = fn()
+            return lambda: r
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            r = fn()
+
+        def join():
+            cur.wait_stream(side)
+            for t in (r if isinstance(r, (tuple, list)) else (r,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+            return r
+        return join
+
     def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
         """R2R: vilmodel.py:690-742."""
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, V, _ = view_img_fts.shape
         H, d = cfg.hidden_size, cfg.obj_v2_size
+        objs = self._fork(lambda: self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types))
         img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
-        obj_rows, O = self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types)
         x = self._pano_tokens(W, img, loc_fts, nav_types)
         pano_masks = _arange(V, x.device)[None] < view_lens[:, None]
         x = self._pano_encoder(W, x, pano_masks.contiguous())
+        obj_rows, O = objs()
         g, b = W['pano.norm.g'], W['pano.norm.b']
         cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
                             lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
@@ -536,6 +563,20 @@ class GlocalTextPathNavCMT(nn.Module):
         h = Fn.linear_grouped([(x, W[k + '.l1.w'], W[k + '.l1.b'], None) for k, x in items], act=ACT_RELU, out_f32=True)
         return [Fn.head_tail(h[j], W[k + '.ln.g'], W[k + '.ln.b'], W[k + '.w2'], W[k + '.b2']) for j, (k, _) in enumerate(items)]
 
+    def _rmf(self, W, g, v, txt):
+        """RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN"""
+        cfg, cd = self.config, self.compute_dtype
+        B, H, dev = g.shape[0], cfg.hidden_size, g.device
+        rows = [g[:, 0], v[:, 0], txt[:, 0]]
+        keys = ['pool.g', 'pool.v', 'pool.t']
+        if torch.is_grad_enabled():
+            pooled = torch.cat(Fn.linear_grouped([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], act=ACT_TANH), -1)
+        else:
+            pooled = torch.empty(B, 3 * H, device=dev, dtype=cd)
+            K.gemm([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], ACT_TANH,
+                   outs=[pooled[:, j * H:(j + 1) * H] for j in range(3)])
+        return Fn.linear_ln(pooled, W['his.map.w'], W['his.map.b'], W['his.ln.g'], W['his.ln.b'], cfg.layer_norm_eps)
+
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
                                     gmap_masks, gmap_pair_dists, gmap_visited_masks, gmap_vpids,
                                     vp_img_embeds, vp_pos_fts, vp_masks, vp_nav_masks, vp_obj_masks, vp_cand_vpids,
@@ -566,6 +607,7 @@ class GlocalTextPathNavCMT(nn.Module):
             items.append(('head.f', torch.cat([g[:, 0], v[:, 0]], 1)))
         if vp_obj_masks is not None:
             items.append(('head.o', v))
+        rmf = self._fork(lambda: self._rmf(W, g, v, txt))          # RMF poolers beside the SAP heads
         sc = self._heads(W, items)
         fuse_raw = sc[2] if self.sap_fuse_linear is not None else None
         if gmap_src is None:
@@ -577,16 +619,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if vp_obj_masks is not None:
             obj_logits = sc[-1].masked_fill(vp_obj_masks.logical_not(), -float('inf'))
 
-        # RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN
-        rows = [g[:, 0], v[:, 0], txt[:, 0]]
-        keys = ['pool.g', 'pool.v', 'pool.t']
-        if torch.is_grad_enabled():
-            pooled = torch.cat(Fn.linear_grouped([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], act=ACT_TANH), -1)
-        else:
-            pooled = torch.empty(B, 3 * H, device=dev, dtype=cd)
-            K.gemm([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], ACT_TANH,
-                   outs=[pooled[:, j * H:(j + 1) * H] for j in range(3)])
-        cls = Fn.linear_ln(pooled, W['his.map.w'], W['his.map.b'], W['his.ln.g'], W['his.ln.b'], cfg.layer_norm_eps)
+        cls = rmf()
         return {'gmap_embeds': g, 'vp_embeds': v, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fl,
                 'obj_logits': obj_logits, 'txt_embeds': txt_embeds, 'cls_embeds': cls}
 
