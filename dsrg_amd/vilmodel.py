@@ -20,6 +20,7 @@ Compute dtype is bfloat16 (default) or float32 (exact-fp32 MFMA: the parity mode
 """
 import math
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -172,6 +173,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self._apply_freeze_flags()
         self._wcache, self._kv_cache = None, None
         self._side_stream, self.overlap_streams = None, True
+        self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
     # ---------------------------------------------------------------- construction helpers
@@ -600,7 +602,12 @@ class GlocalTextPathNavCMT(nn.Module):
                         lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
-        g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
+        if self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams:
+            lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
+            g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
+            v = lj()
+        else:
+            g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
 
         items = [('head.g', g), ('head.l', v)]
         if self.sap_fuse_linear is not None:

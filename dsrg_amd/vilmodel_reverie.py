@@ -23,8 +23,12 @@ class GlocalTextPathNavCMT(_Base):
         B, V, _ = view_img_fts.shape
         H, d = cfg.hidden_size, cfg.obj_v2_size
         dev = view_img_fts.device
+        objs = self._fork(lambda: self._objv2_tokens(W, objv2_img_fts, objv2_lens, objv2_nav_types))
         z = Fn.linear(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], out_f32=True)
-        obj_rows, O = self._objv2_tokens(W, objv2_img_fts, objv2_lens, objv2_nav_types)
+        o1 = None
+        if obj_img_fts is not None:
+            o1 = Fn.linear_ln(obj_img_fts.to(cd), W['objv1.lin.w'], W['objv1.lin.b'], W['objv1.ln.g'], W['objv1.ln.b'], 1e-12)
+        obj_rows, O = objs()
         g, b = W['img.ln.g'], W['img.ln.b']
         cat = self._concat2(lambda o: Fn.layernorm(z, g, b, 1e-12, out_dtype=cd, out=o) if o is not None
                             else Fn.layernorm(z, g, b, 1e-12, out_dtype=cd),
@@ -33,7 +37,6 @@ class GlocalTextPathNavCMT(_Base):
         view = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12)
         if obj_img_fts is not None:
             No = obj_img_fts.shape[1]
-            o1 = Fn.linear_ln(obj_img_fts.to(cd), W['objv1.lin.w'], W['objv1.lin.b'], W['objv1.ln.g'], W['objv1.ln.b'], 1e-12)
             # per-episode [views[:vl] ; objects[:ol] ; zero pad] as one gather (reference: Python loop :727-735)
             T = nav_types.shape[1]
             lens = view_lens + obj_lens
