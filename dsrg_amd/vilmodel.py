@@ -173,7 +173,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self._apply_freeze_flags()
         self._wcache, self._kv_cache = None, None
         self._side_stream, self.overlap_streams = None, True
-        self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams
+        self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '0') == '1'     # opt-in: global / local x-layers on two streams (+2 % at R2R shapes)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
     # ---------------------------------------------------------------- construction helpers
@@ -602,7 +602,10 @@ class GlocalTextPathNavCMT(nn.Module):
                         lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
-        if self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams:
+        # two streams pay when the branches are of similar size (R2R: 20 vs 38 tokens); with one much longer branch
+        # (REVERIE: 20 vs 58) the grouped launches are faster (measured, bench.py --config c3)
+        if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
+                and max(G, Vp) <= 2.7 * min(G, Vp)):
             lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
             g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
             v = lj()
