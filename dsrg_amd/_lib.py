@@ -74,6 +74,7 @@ SIGNATURES = {
     'dsrg_nav_logits_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_igl_blend_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_embed_ln_bwd': (C.c_int, [C.POINTER(EmbedBwdArgs), _P]),
+    'dsrg_segment_wsum': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }

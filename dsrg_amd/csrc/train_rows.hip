@@ -407,6 +407,34 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
   if (a.lno_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlno_gamma + c, col[4 * H + c]); atomicAdd(a.dlno_beta + c, col[5 * H + c]); }
 }
 
+// ---- segment-weighted row gather (pre-training trajectory aggregation, PT/model/vilmodel.py:557-571, 597-635):
+//   out[r, :] = sum_{e in [seg_ptr[r], seg_ptr[r+1])} w[e] * in[idx[e], :]
+// The inputs are two row tables addressed as one (idx < n0 -> in0, else in1[idx - n0]) and so are the outputs
+// (r < m0 -> out0, else out1[r - m0]): the forward gathers panorama-view rows and GAA-pooled rows into graph-map slots,
+// its backward is the same kernel on the transposed incidence (built on the host), so no atomics anywhere.
+template <typename T>
+__global__ __launch_bounds__(256) void segment_wsum_kernel(const T* __restrict__ in0, int ld0, int n0, const T* __restrict__ in1, int ld1,
+                                                           T* __restrict__ out0, int ldo0, int m0, T* __restrict__ out1, int ldo1, int m1,
+                                                           const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ w, int H) {
+  const int lane = threadIdx.x & 63, nv = (H + 255) / 256;
+  const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (r >= m0 + m1) return;
+  float4 acc[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) acc[i] = f4(0.f);
+  for (int e = seg_ptr[r]; e < seg_ptr[r + 1]; ++e) {
+    const int j = idx[e];
+    const float we = w[e];
+    const T* row = j < n0 ? in0 + (size_t)j * ld0 : in1 + (size_t)(j - n0) * ld1;
+#pragma unroll
+    ROWV(i, c) acc[i] = acc[i] + we * ld4(row + c); ENDV
+  }
+  T* o = r < m0 ? out0 + (size_t)r * ldo0 : out1 + (size_t)(r - m0) * ldo1;
+#pragma unroll
+  ROWV(i, c) st4(o + c, acc[i]); ENDV
+}
+
 inline bool okdt(int d) { return d == DSRG_F32 || d == DSRG_BF16; }
 inline bool al(const void* p, uintptr_t m) { return ((uintptr_t)p & m) == 0; }
 inline int strip(int M) { int r = (M + 511) / 512; return r < WPB ? WPB : (r + WPB - 1) / WPB * WPB; }   // <= ~512 workgroups
@@ -523,5 +551,28 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   if (a.dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), grid, block, lds, (hipStream_t)stream, a, rpb);
   else hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, rpb);
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_bwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_segment_wsum(const void* in0, int ld0, int n0, const void* in1, int ld1, int n1, void* out0, int ldo0, int m0,
+                                 void* out1, int ldo1, int m1, const int32_t* seg_ptr, const int32_t* idx, const float* w, int H,
+                                 int dtype, void* stream) {
+  DSRG_CHECK(okdt(dtype) && seg_ptr && n0 >= 0 && n1 >= 0 && m0 >= 0 && m1 >= 0, "dsrg_segment_wsum: bad dtype / null seg_ptr / negative sizes");
+  DSRG_CHECK((n0 == 0 || in0) && (n1 == 0 || in1) && (m0 == 0 || out0) && (m1 == 0 || out1), "dsrg_segment_wsum: null table");
+  DSRG_CHECK(H > 0 && H <= 1024 && H % 4 == 0, "dsrg_segment_wsum: H=%d must be a multiple of 4 and <= 1024", H);
+  DSRG_CHECK((n0 == 0 || (ld0 >= H && ld0 % 4 == 0)) && (n1 == 0 || (ld1 >= H && ld1 % 4 == 0)) && (m0 == 0 || (ldo0 >= H && ldo0 % 4 == 0)) &&
+                 (m1 == 0 || (ldo1 >= H && ldo1 % 4 == 0)), "dsrg_segment_wsum: bad leading dims");
+  const uintptr_t m = dtype == DSRG_BF16 ? 7 : 15;
+  DSRG_CHECK(al(in0, m) && al(in1, m) && al(out0, m) && al(out1, m), "dsrg_segment_wsum: misaligned pointer");
+  if (m0 + m1 == 0) return DSRG_OK;
+  DSRG_CHECK(idx && w, "dsrg_segment_wsum: null idx / w");
+  dim3 grid((m0 + m1 + WPB - 1) / WPB), block(256);
+  if (dtype == DSRG_F32)
+    hipLaunchKernelGGL((segment_wsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)in0, ld0, n0, (const float*)in1, ld1, (float*)out0,
+                       ldo0, m0, (float*)out1, ldo1, m1, seg_ptr, idx, w, H);
+  else
+    hipLaunchKernelGGL((segment_wsum_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)in0, ld0, n0, (const bf16_t*)in1, ld1,
+                       (bf16_t*)out0, ldo0, m0, (bf16_t*)out1, ldo1, m1, seg_ptr, idx, w, H);
+  DSRG_LAUNCH_CHECK("dsrg_segment_wsum");
   return DSRG_OK;
 }

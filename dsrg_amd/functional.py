@@ -569,3 +569,43 @@ def action_tail(nav_logits, targets=None, u=None, ignore_index=-100):
     if targets is not None:
         o['loss'] = o.pop('loss_rows').sum()
     return o
+
+
+# ----------------------------------------------------------------------------- segment-weighted row gather (PT aggregation)
+def csr_by(keys, n, other, w, device):
+    """host: entries (key_e, other_e, w_e) -> CSR over key: (seg_ptr int32 [n+1], idx int32, w fp32) on `device`."""
+    import numpy as np
+    keys, other, w = np.asarray(keys, np.int64), np.asarray(other, np.int64), np.asarray(w, np.float32)
+    order = np.argsort(keys, kind='stable')
+    ptr = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(keys, minlength=n), out=ptr[1:])
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(device)
+    return t(ptr, np.int32), t(other[order], np.int32), t(w[order], np.float32)
+
+
+class _SegmentWsumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in0, in1, fwd_csr, bwd_csr, m):
+        ctx.bwd_csr = bwd_csr
+        ctx.n = (in0.shape[0], in1.shape[0] if in1 is not None else 0)
+        ctx.shapes = (in0.shape, None if in1 is None else in1.shape)
+        return K.segment_wsum(in0, in1, *fwd_csr, m)[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        d0, d1 = K.segment_wsum(K.rows_ok(dout), None, *ctx.bwd_csr, ctx.n[0], ctx.n[1])
+        return d0, d1, None, None, None
+
+
+def segment_wsum(in0, in1, dst, src, w, m):
+    """out[d] = sum_{e: dst_e = d} w_e * cat(in0, in1)[src_e]  (dst, src, w: host index arrays; m output rows).  One kernel
+    forward, the same kernel on the transposed incidence backward."""
+    dev = in0.device
+    in0 = in0.reshape(-1, in0.shape[-1])
+    if in1 is not None:
+        in1 = in1.reshape(-1, in1.shape[-1])
+    fwd = csr_by(dst, m, src, w, dev)
+    if _needs_grad((in0, in1)):
+        n = in0.shape[0] + (in1.shape[0] if in1 is not None else 0)
+        return _SegmentWsumFn.apply(in0, in1, fwd, csr_by(src, n, dst, w, dev), m)
+    return K.segment_wsum(in0, in1, *fwd, m)[0]

@@ -511,3 +511,25 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
     a.E1_rows, a.E2_rows = (E1.shape[0] if E1 is not None else 0), (E2.shape[0] if E2 is not None else 0)
     _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
     return g
+
+
+def segment_wsum(in0, in1, seg_ptr, idx, w, m0, m1=0):
+    """out[r] = sum_e w[e] * cat(in0, in1)[idx[e]] over the entries of segment r -> (out0 [m0,H], out1 [m1,H] or None)."""
+    lib = _lib.load()
+    ref = in0 if in0 is not None else in1
+    _dev(ref)
+    H = ref.shape[-1]
+    n0, ld0 = _rows(in0) if in0 is not None else (0, 0)
+    n1, ld1 = _rows(in1) if in1 is not None else (0, 0)
+    if in0 is not None and in1 is not None and in0.dtype != in1.dtype:
+        raise _lib.DsrgHipError('segment_wsum: both tables must have one dtype')
+    for t, dt in ((seg_ptr, torch.int32), (idx, torch.int32), (w, torch.float32)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise _lib.DsrgHipError('segment_wsum: seg_ptr / idx must be contiguous int32, w contiguous fp32')
+    if seg_ptr.numel() != m0 + m1 + 1:
+        raise _lib.DsrgHipError('segment_wsum: seg_ptr must have m0 + m1 + 1 entries')
+    out0 = torch.empty(m0, H, device=ref.device, dtype=ref.dtype) if m0 else None
+    out1 = torch.empty(m1, H, device=ref.device, dtype=ref.dtype) if m1 else None
+    _lib.check(lib.dsrg_segment_wsum(_p(in0), ld0, n0, _p(in1), ld1, n1, _p(out0), H, m0, _p(out1), H, m1, _p(seg_ptr), _p(idx), _p(w),
+                                     H, _dt(ref), _stream()), 'dsrg_segment_wsum')
+    return out0, out1

@@ -71,9 +71,7 @@ class GlocalTextPathCMT(_Backbone):
         S, V, H = pano.shape
         dev = pano.device
         dst, src, w = self.gmap_aggregation_indices(b['traj_step_lens'], b['traj_vpids'], b['traj_cand_vpids'], b['gmap_vpids'], V, G)
-        flat = torch.cat([pano.reshape(S * V, H), fused], 0)
-        rows = flat.index_select(0, torch.from_numpy(src).to(dev)).float() * torch.from_numpy(w).to(dev)[:, None]
-        img = torch.zeros(B * G, H, device=dev, dtype=torch.float32).index_add_(0, torch.from_numpy(dst).to(dev), rows).to(cd)
+        img = Fn.segment_wsum(pano.reshape(S * V, H), fused, dst, src, w, B * G)      # one gather kernel, no atomics
         g = Fn.embed_ln(B * G, H, cd, dev, base=img, feat=b['gmap_pos_fts'].float().reshape(B * G, -1).contiguous(),
                         Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'], lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']),
                         E1=W['gmap.step'], idx1=b['gmap_step_ids'].reshape(-1)).view(B, G, H)
@@ -84,12 +82,16 @@ class GlocalTextPathCMT(_Backbone):
         cfg, cd = self.config, self.compute_dtype
         S, V, H = pano.shape
         dev = pano.device
-        steps = torch.as_tensor(b['traj_step_lens'], device=dev)
-        last = torch.cumsum(steps, 0) - 1
+        last_np = np.cumsum(np.asarray(b['traj_step_lens'], np.int64)) - 1
+        last = torch.from_numpy(last_np).to(dev)
         B = last.shape[0]
         T = b['vp_pos_fts'].shape[1]                 # = max(last view_len) + 1  ([stop] first)
         vp_lens = b['traj_vp_view_lens'].index_select(0, last) + 1
-        img = torch.cat([torch.zeros(B, 1, H, device=dev, dtype=cd), pano.index_select(0, last)], 1)[:, :T].contiguous()
+        # token (i, 0) = zeros ([stop]), token (i, t >= 1) = view t-1 of trajectory i's last step: the same gather kernel
+        tt = np.arange(1, T)
+        dst = (np.arange(B)[:, None] * T + tt[None]).reshape(-1)
+        src = (last_np[:, None] * V + (tt - 1)[None]).reshape(-1)
+        img = Fn.segment_wsum(pano.reshape(S * V, H), None, dst, src, np.ones(dst.shape[0], np.float32), B * T)
         v = Fn.embed_ln(B * T, H, cd, dev, base=img.reshape(B * T, H), feat=b['vp_pos_fts'].float().reshape(B * T, -1).contiguous(),
                         Wf=W['vp.pos.w'], bf=W['vp.pos.b'], lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, T, H)
         vmask = (torch.arange(T, device=dev)[None] < vp_lens[:, None]).contiguous()

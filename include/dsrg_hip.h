@@ -248,6 +248,16 @@ typedef struct {
 } dsrg_embed_bwd_args_t;
 int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
 
+/* Segment-weighted row gather: out[r,:] = sum_{e in [seg_ptr[r], seg_ptr[r+1])} w[e] * in[idx[e],:].  Replaces the
+ * pre-training graph-map aggregation (dict-of-tensors pooling with Python loops, PT/model/vilmodel.py:597-635: visited
+ * node = the GAA-pooled panorama of its step, unvisited node = mean of the candidate views that saw it) and the
+ * viewpoint-token assembly (:557-571).  Inputs are two row tables addressed as one (idx < n0 -> in0, else in1), outputs
+ * likewise (r < m0 -> out0, else out1); rows of an empty segment are zero.  The backward is the same call on the
+ * transposed incidence (host-built), so no atomics.  seg_ptr has m0 + m1 + 1 entries. */
+int dsrg_segment_wsum(const void* in0, int ld0, int n0, const void* in1, int ld1, int n1, void* out0, int ldo0, int m0,
+                      void* out1, int ldo1, int m1, const int32_t* seg_ptr, const int32_t* idx, const float* w, int H,
+                      int dtype, void* stream);
+
 /* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
  *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].
  * x is `in_dtype` (fp32 pre-LN sums or `dtype`), residual / dy / dz are `dtype`. */

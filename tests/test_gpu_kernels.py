@@ -516,3 +516,31 @@ def test_row_op_backward_kernels(dtype):
                 add = torch.cat([ll[:, :1], add[:, 1:]], 1)
                 return gl, ll, gl + add
             check([gr, lr] + ([fr] if use_f else []), lambda: Fn.nav_logits(gr, lr, fr, gm, gv, vn, src_t, bw_t), nav_ref, 'nav_logits')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_segment_wsum(dtype):
+    """segment-weighted row gather (pre-training graph-map aggregation) forward and backward vs index_select/index_add_."""
+    import numpy as np
+    from dsrg_amd import functional as Fn
+    rng = np.random.RandomState(3)
+    n0, n1, m, H, E = 180, 5, 40, 768, 300
+    a = _r(n0, H, dtype=dtype).requires_grad_(True)
+    b = _r(n1, H, seed=1, dtype=dtype).requires_grad_(True)
+    dst = rng.randint(0, m - 3, E)            # the last rows stay empty -> zeros
+    src = rng.randint(0, n0 + n1, E)
+    w = rng.rand(E).astype(np.float32)
+    out = Fn.segment_wsum(a, b, dst, src, w, m)
+    up = _r(m, H, seed=2)
+    (out.float() * up).sum().backward()
+    ga, gb = a.grad.float().clone(), b.grad.float().clone()
+    a.grad = b.grad = None
+    flat = torch.cat([a.float(), b.float()], 0)
+    rows = flat.index_select(0, torch.from_numpy(src).cuda()) * torch.from_numpy(w).cuda()[:, None]
+    ref = torch.zeros(m, H, device='cuda').index_add_(0, torch.from_numpy(dst).cuda(), rows)
+    (ref * up).sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert (out[m - 3:] == 0).all()
+    for mine, t in ((ga, a), (gb, b)):
+        assert (mine - t.grad.float()).abs().max().item() <= tol * max(1.0, t.grad.abs().max().item())
