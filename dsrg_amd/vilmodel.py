@@ -172,7 +172,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self.init_weights()
         self._apply_freeze_flags()
         self._wcache, self._kv_cache = None, None
-        self._side_stream, self.overlap_streams = None, True
+        self._side_stream, self.overlap_streams, self._fork_depth = None, True, 0
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '0') == '1'     # opt-in: global / local x-layers on two streams (+2 % at R2R shapes)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
@@ -450,20 +450,26 @@ class GlocalTextPathNavCMT(nn.Module):
         encoder and the view encoder of a panorama, or the SAP heads and the RMF poolers of a navigation step, are
         independent chains of small launches that each leave most of the 256 CUs idle; on two streams (two branches of
         the captured HIP graph) they run side by side."""
-        if torch.is_grad_enabled() or not self.overlap_streams:
-            r = fn()
+        if torch.is_grad_enabled() or not self.overlap_streams or self._fork_depth > 0:      # one level only: nested
+            r = fn()                                                                       # forks crash hipStreamEndCapture
             return lambda: r
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        side = self._side_stream
+            self._side_stream = {}
+        side = self._side_stream.get(cur.cuda_stream)          # one side stream per calling stream (forks may nest)
+        if side is None:
+            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            r = fn()
+        self._fork_depth += 1
+        try:
+            with torch.cuda.stream(side):
+                r = fn()
+        finally:
+            self._fork_depth -= 1
 
         def join():
             cur.wait_stream(side)
-            for t in (r if isinstance(r, (tuple, list)) else (r,)):
+            for t in (r if isinstance(r, (tuple, list)) else r.values() if isinstance(r, dict) else (r,)):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(cur)
             return r
