@@ -352,6 +352,16 @@ def main():
             'whole_step_tflops': world * B * a.steps * fl / dt / 1e12,
             'whole_step_frac_of_mfma_peak': B * a.steps * fl / dt / (MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32),
         }
+        # language mode runs once per episode, outside the nav-step metric (SURVEY 8d asks for it separately): eager launches
+        l0 = T(lbs[0], dev)
+        with torch.no_grad():
+            model('language', l0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                model('language', l0)
+            torch.cuda.synchronize()
+        out['language_mode'] = {'ms_per_call': (time.perf_counter() - t1) / 5 * 1e3, 'episodes_per_call': B, 'launch': 'eager'}
         if not a.no_roofline:
             def one_step():
                 with torch.no_grad():

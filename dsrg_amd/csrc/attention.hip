@@ -20,7 +20,20 @@ struct AttnArgs {
   int Nq, Nk; float scale;
   float* lse;   // [B,NH,Nq] log-sum-exp of the scores (NULL unless a backward pass will follow)
   int NH;
+  float p_drop;               // attention-probability dropout (training); 0 = off
+  unsigned long long seed;
 };
+
+// Dropout on the attention probabilities (vilmodel.py:115,150; nn.MultiheadAttention(dropout=)): the keep decision of
+// element (b, h, q, k) is a counter-based hash of (seed, flat index), so the backward recomputes the same mask and no
+// mask tensor exists.  Returns 1/(1-p) for a kept element, 0 for a dropped one.
+__device__ __forceinline__ float drop_keep(unsigned long long seed, size_t idx, float p, float inv_keep) {
+  unsigned long long z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
+}
 
 // up to DSRG_ATTN_MAX_GROUPS independent problems (same B, NH, mask mode, dtype) in one launch: blockIdx.x walks the
 // query blocks of problem 0, then problem 1, ...
@@ -36,7 +49,7 @@ struct AttnGroup {
   const AttnArgs& a = grp.a[gsel];                               \
   const int bx = (int)blockIdx.x - grp.start[gsel];
 
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
@@ -106,7 +119,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
       const float p = (s == -INFINITY) ? 0.f : __expf(s - mn);
       l[i] = l[i] * alpha + wave_sum(p);
       m[i] = mn;
-      Ps[wave * KT + lane] = p;                     // wave-private row: no barrier needed, wave is in lockstep
+      const float pk = (DROP && p != 0.f)
+                           ? p * drop_keep(a.seed, (((size_t)b * a.NH + h) * a.Nq + qg) * a.Nk + key, a.p_drop, 1.0f / (1.0f - a.p_drop)) : p;
+      Ps[wave * KT + lane] = pk;                    // wave-private row: no barrier needed, wave is in lockstep
       __builtin_amdgcn_wave_barrier();
       float acc = o[i] * alpha;
 #pragma unroll 8
@@ -146,6 +161,7 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnGroup grp) {
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
@@ -270,6 +286,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnGroup grp
         }
       }
     l_run = l_run * alpha + psum;
+    if (DROP && qrow < a.Nq) {                        // the normaliser keeps the undropped sum; only P.V sees the mask
+      const float ik = 1.0f / (1.0f - a.p_drop);
+      const size_t rbase = (((size_t)b * a.NH + h) * a.Nq + qrow) * a.Nk + k0;
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+        if (t < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kl = t * 16 + 4 * g + r;
+            if (kl < nk) s[t][r] *= drop_keep(a.seed, rbase + kl, a.p_drop, ik);
+          }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] *= alpha;
     // ---- O^T += V^T · P^T
@@ -398,6 +427,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs
       float dist = 0.f;
       if (a.dists && !dead) { dist = a.dists[((size_t)b * a.Nq + qg) * a.Nk + key]; s += dist * sw + sb; }
       const float p = dead ? 0.f : __expf(s - lse[i]);
+      if (a.p_drop > 0.f && !dead)
+        dp *= drop_keep(a.seed, (((size_t)b * a.NH + h) * a.Nq + qg) * a.Nk + key, a.p_drop, 1.0f / (1.0f - a.p_drop));
       const float ds = p * (dp - delta[i]);
       gsw += ds * dist; gsb += ds;
       Ds[wave * KT + lane] = ds;
@@ -486,13 +517,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
       s = s * a.scale + mterm;
       if (a.dists && !dead) s += a.dists[((size_t)b * a.Nq + qg) * a.Nk + key] * sw + sb;
       const float p = dead ? 0.f : __expf(s - Ls[i]);
+      float keep = 1.f;
+      if (a.p_drop > 0.f && !dead)
+        keep = drop_keep(a.seed, (((size_t)b * a.NH + h) * a.Nq + qg) * a.Nk + key, a.p_drop, 1.0f / (1.0f - a.p_drop));
+      dp *= keep;
+      const float pv = p * keep;                    // what multiplied V in the forward
       const float ds = p * (dp - Dl[i]) * a.scale;
 #pragma unroll
       for (int c = 0; c < DH; c += 4) {
         const float4 qq = *reinterpret_cast<const float4*>(&Qs[i * DH + c]);
         const float4 gg = *reinterpret_cast<const float4*>(&Gs[i * DH + c]);
         dk[c] = fmaf(ds, qq.x, dk[c]); dk[c + 1] = fmaf(ds, qq.y, dk[c + 1]); dk[c + 2] = fmaf(ds, qq.z, dk[c + 2]); dk[c + 3] = fmaf(ds, qq.w, dk[c + 3]);
-        dv[c] = fmaf(p, gg.x, dv[c]); dv[c + 1] = fmaf(p, gg.y, dv[c + 1]); dv[c + 2] = fmaf(p, gg.z, dv[c + 2]); dv[c + 3] = fmaf(p, gg.w, dv[c + 3]);
+        dv[c] = fmaf(pv, gg.x, dv[c]); dv[c + 1] = fmaf(pv, gg.y, dv[c + 1]); dv[c + 2] = fmaf(pv, gg.z, dv[c + 2]); dv[c + 3] = fmaf(pv, gg.w, dv[c + 3]);
       }
     }
   }
@@ -529,8 +565,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 }  // namespace
 
 extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, int nproblems, int mask_mode,
-                                          const float* sprel_w, const float* sprel_b, int B, int NH, float scale, int dtype,
-                                          void* stream) {
+                                          const float* sprel_w, const float* sprel_b, int B, int NH, float scale, float p_drop,
+                                          uint64_t seed, int dtype, void* stream) {
+  DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_attention_fwd: p_drop=%g out of [0,1)", (double)p_drop);
   DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_ATTN_MAX_GROUPS, "dsrg_attention_fwd: nproblems=%d out of [1,%d]", nproblems,
              DSRG_ATTN_MAX_GROUPS);
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_fwd: bad dtype %d", dtype);
@@ -556,7 +593,7 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
               p.o_rs % 4 == 0 && p.o_bs % 4 == 0 && (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.O & 7) == 0;
     grp.a[grp.n++] = AttnArgs{p.Q, p.K, p.V, p.O, p.q_bs, p.k_bs, p.v_bs, p.o_bs, p.q_rs, p.k_rs, p.v_rs, p.o_rs,
                               mask_mode == DSRG_MASK_NONE ? nullptr : p.kmask, mask_mode, p.pair_dists, sprel_w, sprel_b, p.Nq, p.Nk, scale,
-                              p.lse, NH};
+                              p.lse, NH, p_drop, seed + 0x632BE59BD9B4E019ull * (unsigned long long)i};
   }
   if (B == 0 || grp.n == 0) return DSRG_OK;
   const int qpb = mfma_ok ? 64 : QPB;           // query rows per workgroup
@@ -564,9 +601,18 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
   for (int i = 0; i < grp.n; ++i) { grp.start[i] = blocks; blocks += (grp.a[i].Nq + qpb - 1) / qpb; }
   grp.start[grp.n] = blocks;
   dim3 grid(blocks, NH, B), block(256);
-  if (mfma_ok) hipLaunchKernelGGL(attention_mfma_kernel, grid, block, 0, (hipStream_t)stream, grp);
-  else if (dtype == DSRG_F32) hipLaunchKernelGGL((attention_kernel<float>), grid, block, 0, (hipStream_t)stream, grp);
-  else hipLaunchKernelGGL((attention_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, grp);
+  const bool drop = p_drop > 0.f;      // the dropout variants are separate instantiations: the inference kernels carry none of it
+  hipStream_t st = (hipStream_t)stream;
+  if (mfma_ok) {
+    if (drop) hipLaunchKernelGGL((attention_mfma_kernel<true>), grid, block, 0, st, grp);
+    else hipLaunchKernelGGL((attention_mfma_kernel<false>), grid, block, 0, st, grp);
+  } else if (dtype == DSRG_F32) {
+    if (drop) hipLaunchKernelGGL((attention_kernel<float, true>), grid, block, 0, st, grp);
+    else hipLaunchKernelGGL((attention_kernel<float, false>), grid, block, 0, st, grp);
+  } else {
+    if (drop) hipLaunchKernelGGL((attention_kernel<bf16_t, true>), grid, block, 0, st, grp);
+    else hipLaunchKernelGGL((attention_kernel<bf16_t, false>), grid, block, 0, st, grp);
+  }
   DSRG_LAUNCH_CHECK("dsrg_attention_fwd");
   return DSRG_OK;
 }
@@ -575,9 +621,10 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
                                   const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
                                   const uint8_t* kmask, int mask_mode, const float* pair_dists,
                                   const float* sprel_w, const float* sprel_b,
-                                  int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream) {
+                                  int B, int NH, int Nq, int Nk, float scale, float* lse, float p_drop, uint64_t seed, int dtype,
+                                  void* stream) {
   const dsrg_attn_problem_t p{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, kmask, pair_dists, lse, Nq, Nk};
-  return dsrg_attention_fwd_grouped(&p, 1, mask_mode, sprel_w, sprel_b, B, NH, scale, dtype, stream);
+  return dsrg_attention_fwd_grouped(&p, 1, mask_mode, sprel_w, sprel_b, B, NH, scale, p_drop, seed, dtype, stream);
 }
 
 extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
@@ -586,7 +633,8 @@ extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const v
                                   const uint8_t* kmask, int mask_mode, const float* pair_dists,
                                   const float* sprel_w, const float* sprel_b,
                                   void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
-                                  int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream) {
+                                  int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+  DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_attention_bwd: p_drop=%g out of [0,1)", (double)p_drop);
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_bwd: bad dtype %d", dtype);
   DSRG_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws, "dsrg_attention_bwd: null pointer");
   DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0 && Nk >= 1 && B <= 65535 && NH <= 65535, "dsrg_attention_bwd: bad dims");
@@ -599,7 +647,7 @@ extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const v
              "dsrg_attention_bwd: misaligned pointer");
   if (B == 0 || Nq == 0) return DSRG_OK;
   AttnBwdArgs ba{{Q, K, V, const_cast<void*>(O), q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask,
-                  mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH},
+                  mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH, p_drop, seed},
                  dO, do_bs, do_rs, dQ, dK, dV, delta_ws, dsprel};
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((Nq + QPB - 1) / QPB, NH, B), gk((Nk + KT - 1) / KT, NH, B), block(256);

@@ -340,39 +340,49 @@ def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0):
 
 
 # ----------------------------------------------------------------------------- attention
+def dropout_seed():
+    """63-bit seed for the in-kernel attention dropout, drawn from torch's CPU generator (follows torch.manual_seed)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, kmask, dists, sw, sb, nh, mask_mode, scale):
-        out, lse = K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sw, sb, scale, want_lse=True)
-        ctx.cfg = (nh, mask_mode, scale)
+    def forward(ctx, q, k, v, kmask, dists, sw, sb, nh, mask_mode, scale, p_drop, seed):
+        out, lse = K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sw, sb, scale, want_lse=True,
+                               p_drop=p_drop, seed=seed)
+        ctx.cfg = (nh, mask_mode, scale, p_drop, seed)
         ctx.save_for_backward(q, k, v, out, lse, kmask, dists, sw, sb)
         return out
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, out, lse, kmask, dists, sw, sb = ctx.saved_tensors
-        nh, mask_mode, scale = ctx.cfg
-        dq, dk, dv, dsp = K.attention_bwd(q, k, v, out, do.to(q.dtype), lse, nh, kmask, mask_mode, dists, sw, sb, scale)
+        nh, mask_mode, scale, p_drop, seed = ctx.cfg
+        dq, dk, dv, dsp = K.attention_bwd(q, k, v, out, do.to(q.dtype), lse, nh, kmask, mask_mode, dists, sw, sb, scale, p_drop, seed)
         dsw = dsb = None
         if dsp is not None:
             dsw, dsb = dsp[0:1].reshape(sw.shape).to(sw.dtype), dsp[1:2].reshape(sb.shape).to(sb.dtype)
-        return dq, dk, dv, None, None, dsw, dsb, None, None, None
+        return dq, dk, dv, None, None, dsw, dsb, None, None, None, None, None
 
 
-def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125):
+def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0, seed=None):
+    """Fused attention.  p_drop > 0: dropout on the attention probabilities inside the kernel (training)."""
+    if p_drop > 0.0 and seed is None:
+        seed = dropout_seed()
     if _needs_grad((q, k, v, sprel_w, sprel_b)):
-        return _AttentionFn.apply(q, k, v, kmask, dists, sprel_w, sprel_b, nh, mask_mode, scale)
-    return K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sprel_w, sprel_b, scale)
+        return _AttentionFn.apply(q, k, v, kmask, dists, sprel_w, sprel_b, nh, mask_mode, scale, float(p_drop), seed or 0)
+    return K.attention(q, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sprel_w, sprel_b, scale,
+                       p_drop=p_drop, seed=seed or 0)
 
 
-def attention_grouped(problems, nh, mask_mode=MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125):
+def attention_grouped(problems, nh, mask_mode=MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0):
     """problems: list of (q, k, v, kmask, dists|None): one launch when no gradient is needed (the two branches of an
     x-layer), one differentiable call per problem otherwise."""
     flat = [t for p in problems for t in p[:3]] + [sprel_w, sprel_b]
     if _needs_grad(flat) or len(problems) > _lib.ATTN_MAX_GROUPS:
-        return [attention(q, k, v, nh, km, mask_mode, d, sprel_w if d is not None else None, sprel_b if d is not None else None, scale)
-                for q, k, v, km, d in problems]
-    return K.attention_grouped(problems, nh, mask_mode, sprel_w, sprel_b, scale)
+        return [attention(q, k, v, nh, km, mask_mode, d, sprel_w if d is not None else None, sprel_b if d is not None else None, scale,
+                          p_drop) for q, k, v, km, d in problems]
+    return K.attention_grouped(problems, nh, mask_mode, sprel_w, sprel_b, scale, p_drop, dropout_seed() if p_drop > 0.0 else 0)
 
 
 # ----------------------------------------------------------------------------- layernorm

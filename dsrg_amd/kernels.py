@@ -117,7 +117,7 @@ def gemm_replay(rec):
 
 
 def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125,
-              want_lse=False):
+              want_lse=False, p_drop=0.0, seed=0):
     """q [B,Nq,nh*64], k/v [B,Nk,nh*64] views (row/batch strides free, last dim contiguous)."""
     lib = _lib.load()
     _dev(q)
@@ -138,11 +138,11 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     _lib.check(lib.dsrg_attention_fwd(
         _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1),
         _p(out), out.stride(0), out.stride(1), _p(kmask), mask_mode, _p(dists), _p(sprel_w), _p(sprel_b),
-        B, nh, Nq, Nk, float(scale), _p(lse), _dt(q), _stream()), 'dsrg_attention_fwd')
+        B, nh, Nq, Nk, float(scale), _p(lse), float(p_drop), int(seed), _dt(q), _stream()), 'dsrg_attention_fwd')
     return (out, lse) if want_lse else out
 
 
-def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125):
+def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0, seed=0):
     """problems: list (<= 4) of (q, k, v, kmask|None, dists|None) sharing B, nh, mask mode and dtype -> outputs, ONE launch."""
     lib = _lib.load()
     n = len(problems)
@@ -172,12 +172,12 @@ def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, spre
         a.q_bs, a.k_bs, a.v_bs, a.o_bs = bs(q), bs(k), bs(v), out.stride(0)
         a.q_rs, a.k_rs, a.v_rs, a.o_rs = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
         a.kmask, a.pair_dists, a.lse, a.Nq, a.Nk = _p(kmask), _p(dists), None, Nq, Nk
-    _lib.check(lib.dsrg_attention_fwd_grouped(arr, n, mask_mode, _p(sprel_w), _p(sprel_b), B, nh, float(scale), _dt(q0), _stream()),
-               'dsrg_attention_fwd_grouped')
+    _lib.check(lib.dsrg_attention_fwd_grouped(arr, n, mask_mode, _p(sprel_w), _p(sprel_b), B, nh, float(scale), float(p_drop), int(seed), _dt(q0),
+                                              _stream()), 'dsrg_attention_fwd_grouped')
     return outs
 
 
-def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125):
+def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125, p_drop=0.0, seed=0):
     """-> dq, dk, dv (contiguous), dsprel fp32 [2] (or None)"""
     lib = _lib.load()
     B, Nq, _ = q.shape
@@ -192,8 +192,8 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     _lib.check(lib.dsrg_attention_bwd(
         _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
         _p(do), bs(do), do.stride(1), _p(lse), _p(kmask), mask_mode if kmask is not None else _lib.MASK_NONE, _p(dists),
-        _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), _dt(q), _stream()),
-        'dsrg_attention_bwd')
+        _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), float(p_drop), int(seed),
+        _dt(q), _stream()), 'dsrg_attention_bwd')
     return dq, dk, dv, dsp
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 2
+#define DSRG_ABI_VERSION 3
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -65,13 +65,17 @@ int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems /*host*/, int nproblem
  *   (FT/vilmodel.py:711-712 -> :143).
  * pair_dists: fp32 [B,Nq,Nk] or NULL; sprel_w/sprel_b: device pointers to the two scalars of
  * sprel_linear; the bias w·d+b (FT/vilmodel.py:757-759, 462-463) is formed in the kernel.
- * lse: fp32 [B,NH,Nq] or NULL; when given, the log-sum-exp of each score row is stored for dsrg_attention_bwd. */
+ * lse: fp32 [B,NH,Nq] or NULL; when given, the log-sum-exp of each score row is stored for dsrg_attention_bwd.
+ * p_drop / seed: dropout on the attention probabilities (training; FT/vilmodel.py:115,150,342, transformer.py:138): the
+ * keep decision of element (b,h,q,k) is a counter-based hash of (seed, index), recomputed by dsrg_attention_bwd when
+ * it is given the same p_drop and seed; 0 = off. */
 enum { DSRG_MASK_NONE = 0, DSRG_MASK_NEG10000 = 1, DSRG_MASK_NEGINF = 2, DSRG_MASK_PLUS1 = 3 };
 int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
                        const void* V, int64_t v_bs, int v_rs, void* O, int64_t o_bs, int o_rs,
                        const uint8_t* kmask, int mask_mode, const float* pair_dists,
                        const float* sprel_w, const float* sprel_b,
-                       int B, int NH, int Nq, int Nk, float scale, float* lse, int dtype, void* stream);
+                       int B, int NH, int Nq, int Nk, float scale, float* lse, float p_drop, uint64_t seed, int dtype,
+                       void* stream);
 
 /* The same for up to DSRG_ATTN_MAX_GROUPS independent problems that share B, NH, mask mode, scale and dtype, in ONE
  * launch: the global and the local branch of an x-layer attend at the same point (FT/vilmodel.py:540-549). */
@@ -87,8 +91,8 @@ typedef struct {
   int32_t Nq, Nk;
 } dsrg_attn_problem_t;
 int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems /*host*/, int nproblems, int mask_mode,
-                               const float* sprel_w, const float* sprel_b, int B, int NH, float scale, int dtype,
-                               void* stream);
+                               const float* sprel_w, const float* sprel_b, int B, int NH, float scale, float p_drop,
+                               uint64_t seed /* problem i uses seed + i * 0x632BE59BD9B4E019 */, int dtype, void* stream);
 
 /* ---- LayerNorm over the last dim (wave reduction, fp32 statistics) -------------------------------
  * out = LN(x [+ residual]) * gamma + beta.  Replaces BertLayerNorm / nn.LayerNorm
@@ -210,7 +214,7 @@ int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int
                        const uint8_t* kmask, int mask_mode, const float* pair_dists,
                        const float* sprel_w, const float* sprel_b,
                        void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
-                       int B, int NH, int Nq, int Nk, float scale, int dtype, void* stream);
+                       int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* Backward of the row kernels (each recomputes its forward values; parameter gradients are accumulated with float
  * atomics into fp32 buffers the caller has zeroed; activation gradients are written in the storage dtype). */

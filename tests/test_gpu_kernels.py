@@ -544,3 +544,63 @@ def test_segment_wsum(dtype):
     assert (out[m - 3:] == 0).all()
     for mine, t in ((ga, a), (gb, b)):
         assert (mine - t.grad.float()).abs().max().item() <= tol * max(1.0, t.grad.abs().max().item())
+
+
+def _keep_mask(seed, B, nh, Nq, Nk, p):
+    """numpy restatement of drop_keep() (attention.hip): splitmix64 finaliser of seed + (idx+1)*golden, top 24 bits -> u"""
+    import numpy as np
+    idx = np.arange(B * nh * Nq * Nk, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        z = np.uint64(seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy((u >= np.float32(p)).reshape(B, nh, Nq, Nk)).cuda()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [(3, 12, 20, 80, 1, False), (2, 12, 38, 38, 1, True), (2, 2, 108, 108, 3, False),
+                                                    (2, 12, 36, 36, 2, False), (2, 12, 70, 250, 1, False)])
+def test_attention_dropout(K, dtype, B, nh, Nq, Nk, mode, sprel):
+    """in-kernel dropout on the attention probabilities: forward and backward against torch with the SAME keep mask (the
+    mask is a counter-based hash, restated in numpy above); the normaliser uses the undropped probabilities, like
+    nn.Dropout applied after the softmax."""
+    H, p, seed = nh * 64, 0.1, 0x1234_5678_9ABC
+    if Nq == Nk:
+        qkv = _r(B, Nq, 3 * H, dtype=dtype)
+        q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
+    else:
+        q, kv = _r(B, Nq, H, dtype=dtype), _r(B, Nk, 2 * H, seed=1, dtype=dtype)
+        k, v = kv[..., :H], kv[..., H:]
+    lens = torch.randint(1, Nk + 1, (B,), generator=torch.Generator().manual_seed(5)); lens[0] = Nk
+    kmask = (torch.arange(Nk)[None] < lens[:, None]).cuda()
+    dists = (_r(B, Nq, Nk, seed=7).abs() * 5) if sprel else None
+    sw, sb = (torch.tensor([-0.21]).cuda(), torch.tensor([0.07]).cuda()) if sprel else (None, None)
+    do = _r(B, Nq, H, seed=11, dtype=dtype)
+    out, lse = K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, want_lse=True, p_drop=p, seed=seed)
+    dq, dk, dv, _ = K.attention_bwd(q, k, v, out, do, lse, nh, kmask, mode, dists, sw, sb, p_drop=p, seed=seed)
+    keep = _keep_mask(seed, B, nh, Nq, Nk, p)
+    assert 0.85 < keep.float().mean().item() < 0.95
+    leaves = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    sp = lambda t: t.reshape(B, t.shape[1], nh, 64).permute(0, 2, 1, 3)
+    s = sp(leaves[0]) @ sp(leaves[1]).transpose(-1, -2) * 0.125
+    if mode == 1:
+        s = s + (1.0 - kmask[:, None, None].float()) * -10000.0
+    elif mode == 2:
+        s = s.masked_fill(~kmask[:, None, None], float('-inf'))
+    elif mode == 3:
+        s = s + kmask[:, None, None].float()
+    if dists is not None:
+        s = s + (dists * sw + sb)[:, None]
+    pr = torch.softmax(s, -1) * keep.float() / (1.0 - p)
+    ref = (pr @ sp(leaves[2])).permute(0, 2, 1, 3).reshape(B, Nq, H)
+    ref.backward(do.float())
+    fp32 = dtype == torch.float32
+    assert (out.float() - ref).abs().max().item() <= (3e-5 if fp32 else 3e-2)
+    for name, got, want in (('dq', dq, leaves[0].grad), ('dk', dk, leaves[1].grad), ('dv', dv, leaves[2].grad)):
+        err = (got.float() - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        assert err <= (2e-4 if fp32 else 4e-2), (name, err)
+    # a different seed gives a different mask; p = 0 is exactly the plain kernel
+    assert not torch.equal(out, K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, p_drop=p, seed=seed + 1))
+    assert torch.equal(K.attention(q, k, v, nh, kmask, mode, dists, sw, sb), K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, p_drop=0.0, seed=99))
