@@ -39,6 +39,17 @@ class EmbedBwdArgs(C.Structure):
                                                                                    ('E2_rows', C.c_int32)]
 
 
+class GraphState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('pos', 'dist', 'point', 'visited', 'step_id', 'emb_sum', 'emb_cnt', 'n_nodes')] + \
+               [('N', C.c_int32), ('H', C.c_int32)]
+
+
+class GraphNavOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('gmap_img', 'gmap_step_ids', 'gmap_pos_fts', 'gmap_pair_dists', 'gmap_masks', 'gmap_visited',
+                                          'gmap_slots', 'gmap_src', 'bw_mask', 'vp_pos_fts', 'no_vp_left', 'gmap_len')] + \
+               [('G', C.c_int32), ('Vp', C.c_int32)]
+
+
 class LnProblem(C.Structure):
     _fields_ = [('x', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('out', C.c_void_p),
                 ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32)]
@@ -75,6 +86,10 @@ SIGNATURES = {
     'dsrg_igl_blend_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_embed_ln_bwd': (C.c_int, [C.POINTER(EmbedBwdArgs), _P]),
     'dsrg_segment_wsum': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'dsrg_graph_reset': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_graph_observe': (C.c_int, [C.POINTER(GraphState), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_graph_update_embeds': (C.c_int, [C.POINTER(GraphState), _P, _P, _P, _P, _I, _P, _L, _I, _P, _I, _I, _I, _P]),
+    'dsrg_graph_nav_inputs': (C.c_int, [C.POINTER(GraphState), C.POINTER(GraphNavOut), _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }

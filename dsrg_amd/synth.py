@@ -293,3 +293,46 @@ def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V
                 ga[i], la[i] = opts[int(pickc[i]) % len(opts)]
         batch['global_act_labels'], batch['local_act_labels'] = ga, la
     return batch
+
+
+# --------------------------------------------------------------------------
+# rollouts on a synthetic connectivity graph (what the simulator's observations look like to the graph-map code,
+# finetune_src/r2r/env.py:_get_obs -> agent.py:406-408, 565-569)
+# --------------------------------------------------------------------------
+def episode_walks(B, T, seed=0, world=40, max_cand=6):
+    """B episodes of T observations.  Returns obs[t][i] = {'viewpoint', 'position' (x,y,z), 'heading', 'elevation',
+    'candidate': [{'viewpointId', 'position'}]} and ended[t][i] (an episode keeps returning its last observation once ended,
+    as the environment does).  Worlds are random point sets joined to their nearest neighbours; the walk prefers
+    unvisited neighbours, so graphs grow by 2-6 nodes a step and some nodes are seen from several places."""
+    obs, ended = [[None] * B for _ in range(T)], np.zeros((T, B), bool)
+    for i in range(B):
+        pos = uniform('walk_pos%d' % i, (world, 3), seed, -12.0, 12.0).astype(np.float64)
+        pos[:, 2] = uniform('walk_z%d' % i, (world,), seed, -1.5, 1.5)
+        d = np.sqrt(((pos[:, None] - pos[None]) ** 2).sum(-1))
+        deg = integers('walk_deg%d' % i, (world,), 2, max_cand + 1, seed)
+        nbr = [set(np.argsort(d[v])[1:1 + int(deg[v])].tolist()) for v in range(world)]
+        for v in range(world):                      # make it symmetric, keep the cap
+            for u in list(nbr[v]):
+                if len(nbr[u]) < max_cand:
+                    nbr[u].add(v)
+        nbr = [[u for u in sorted(nbr[v]) if v in nbr[u]] or [int(np.argsort(d[v])[1])] for v in range(world)]
+        pick = uniform('walk_pick%d' % i, (T,), seed, 0.0, 1.0)
+        head = uniform('walk_head%d' % i, (T,), seed, 0.0, 6.2831853).astype(np.float64)
+        elev = uniform('walk_elev%d' % i, (T,), seed, -0.5, 0.5).astype(np.float64)
+        stop_at = int(integers('walk_stop%d' % i, (1,), max(2, T // 2), T + 3, seed)[0])
+        cur, seen, name = int(integers('walk_start%d' % i, (1,), 0, world, seed)[0]), set(), lambda v: 'e%d_%02d' % (i, v)
+        for t in range(T):
+            if t >= stop_at:
+                ended[t, i] = True
+                obs[t][i] = obs[t - 1][i]
+                continue
+            seen.add(cur)
+            order = np.argsort(uniform('walk_ord%d_%d' % (i, t), (len(nbr[cur]),), seed))
+            cands = [nbr[cur][j] for j in order]
+            obs[t][i] = {'viewpoint': name(cur), 'position': tuple(float(x) for x in pos[cur]), 'heading': float(head[t]),
+                         'elevation': float(elev[t]),
+                         'candidate': [{'viewpointId': name(u), 'position': tuple(float(x) for x in pos[u])} for u in cands]}
+            fresh = [u for u in cands if u not in seen]
+            pool = fresh if (fresh and pick[t] < 0.8) else cands
+            cur = pool[int(pick[t] * 1e6) % len(pool)]
+    return obs, ended

@@ -179,6 +179,54 @@ int dsrg_action_tail_fwd(const float* logits, int ld, const int64_t* targets, in
                          float* stop_prob, int32_t* argmax, int32_t* sample, float* entropy, float* loss_rows,
                          float* dlogits, int B, int N, void* stream);
 
+/* ---- device-resident graph map + navigation-input assembly ------------------------
+ * Replaces GraphMap / FloydGraph (FT/models/graph_utils.py:42-148), the per-step graph / node-embedding updates of the
+ * rollout (FT/r2r/agent.py:406-408, 434-451, 565-569) and the builders _nav_gmap_variable / _nav_vp_variable (:157-278).
+ * The host keeps only the viewpoint-id -> slot dictionaries (slot = insertion order into node_positions; slot 0 is the
+ * start viewpoint) and hands over, per step, slots + positions of the current node and its candidates.  Distances are
+ * double, compared exactly as the reference's Python floats.  N <= 128 nodes per episode. */
+typedef struct {
+  double* pos;        /* [B,N,3] */
+  double* dist;       /* [B,N,N] 95959595 = unknown */
+  int32_t* point;     /* [B,N,N] via-node, -1 = direct / unknown */
+  uint8_t* visited;   /* [B,N] */
+  int32_t* step_id;   /* [B,N] */
+  float* emb_sum;     /* [B,N,H] */
+  int32_t* emb_cnt;   /* [B,N] */
+  int32_t* n_nodes;   /* [B] */
+  int32_t N, H;
+} dsrg_graph_state_t;
+typedef struct {
+  void* gmap_img;          /* [B,G,H] storage dtype: zeros, [MEM], mean node embeddings (visited, then unvisited), zero pad */
+  int64_t* gmap_step_ids;  /* [B,G] */
+  float* gmap_pos_fts;     /* [B,G,7] */
+  float* gmap_pair_dists;  /* [B,G,G] */
+  uint8_t* gmap_masks;     /* [B,G] column 1 ([MEM]) false, FT/r2r/agent.py:211 */
+  uint8_t* gmap_visited;   /* [B,G] */
+  int32_t* gmap_slots;     /* [B,G] node slot of each token, -1 for [stop] / [MEM] / padding */
+  int32_t* gmap_src;       /* [B,G] fusion indices for dsrg_nav_logits_fwd */
+  uint8_t* bw_mask;        /* [B,Vp] */
+  float* vp_pos_fts;       /* [B,Vp,14] */
+  uint8_t* no_vp_left;     /* [B] */
+  int32_t* gmap_len;       /* [B] */
+  int32_t G, Vp;           /* padded widths chosen by the caller (G >= max gmap_len) */
+} dsrg_graph_nav_out_t;
+int dsrg_graph_reset(double* pos, double* dist, int32_t* point, uint8_t* visited, int32_t* step_id, float* emb_sum,
+                     int32_t* emb_cnt, int32_t* n_nodes, int B, int N, int H, void* stream);
+/* update_graph(ob) for episodes with graph_active, then node_step_ids[cur] = step_value for those with step_active.
+ * cand_slot [B,Cmax], cur_pos [B,3], cand_pos [B,Cmax,3] (double); n_nodes_new = node count after this observation. */
+int dsrg_graph_observe(const dsrg_graph_state_t* st, const uint8_t* graph_active, const uint8_t* step_active,
+                       const int32_t* cur_slot, const int32_t* n_nodes_new, const int32_t* ncand, const int32_t* cand_slot,
+                       const double* cur_pos, const double* cand_pos, int Cmax, int step_value, int B, void* stream);
+/* node embeddings: current node <- fused (rewrite); every unvisited candidate j accumulates pano[b, j, :]. */
+int dsrg_graph_update_embeds(const dsrg_graph_state_t* st, const uint8_t* active, const int32_t* cur_slot, const int32_t* ncand,
+                             const int32_t* cand_slot, int Cmax, const void* pano, int64_t pano_bs, int pano_rs,
+                             const void* fused, int fused_rs, int B, int dtype, void* stream);
+/* all graph-side inputs of forward(mode='navigation') in one launch; mem = last cls_embeds [B,H] or NULL (step 0). */
+int dsrg_graph_nav_inputs(const dsrg_graph_state_t* st, const dsrg_graph_nav_out_t* out, const int32_t* cur_slot,
+                          const double* heading, const double* elevation, const int32_t* ncand, const int32_t* cand_slot,
+                          int Cmax, const void* mem, int mem_rs, int B, int dtype, void* stream);
+
 /* ---- IGL gate: w = sigmoid(aug·wa + ba + x·wo + bo); out = w·aug + (1-w)·x --------------------------
  * FT/vilmodel.py:525-528.  aug/x/out [M,H] `dtype`; wa/wo fp32 [H]; ba/bo fp32 [1]. */
 int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const float* ba, const float* wo,
