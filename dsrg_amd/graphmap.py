@@ -52,42 +52,36 @@ class BatchedGraphMap:
     # ------------------------------------------------------------------ host bookkeeping + packing of one observation
     def _pack(self, obs, active):
         B, Cm = self.B, self.C
-        cur = np.zeros(B, np.int32); ncand = np.zeros(B, np.int32); n_new = np.zeros(B, np.int32)
-        cand = np.zeros((B, Cm), np.int32)
-        cpos = np.zeros((B, 3), np.float64); kpos = np.zeros((B, Cm, 3), np.float64)
-        head = np.zeros(B, np.float64); elev = np.zeros(B, np.float64)
+        # two packed host buffers -> two H2D copies: int32 [cur | ncand | n_new | cand], float64 [cpos | head | elev | kpos]
+        ib = np.zeros(B * (3 + Cm), np.int32)
+        fb = np.zeros(B * (5 + 3 * Cm), np.float64)
+        cur, ncand, n_new, cand = ib[:B], ib[B:2 * B], ib[2 * B:3 * B], ib[3 * B:].reshape(B, Cm)
+        cpos, head, elev, kpos = fb[:3 * B].reshape(B, 3), fb[3 * B:4 * B], fb[4 * B:5 * B], fb[5 * B:].reshape(B, Cm, 3)
         for i, ob in enumerate(obs):
             sl, nm = self.slots[i], self.names[i]
-
-            def slot(vp):
-                s = sl.get(vp)
-                if s is None:
-                    s = sl[vp] = len(nm)
-                    nm.append(vp)
-                    if s >= self.N:
-                        raise _lib.DsrgHipError('BatchedGraphMap: episode %d exceeds max_nodes=%d' % (i, self.N))
-                return s
             cc = ob['candidate']
             if len(cc) > Cm:
                 raise _lib.DsrgHipError('BatchedGraphMap: %d candidates (max_cand=%d)' % (len(cc), Cm))
             if active[i]:
-                cur[i] = slot(ob['viewpoint'])
-                for j, c in enumerate(cc):
-                    cand[i, j] = slot(c['viewpointId'])
-            else:                                   # an ended episode repeats its last observation: all ids are known
-                cur[i] = sl[ob['viewpoint']]
-                for j, c in enumerate(cc):
-                    cand[i, j] = sl[c['viewpointId']]
+                for vp in [ob['viewpoint']] + [c['viewpointId'] for c in cc]:       # insertion order of node_positions
+                    if vp not in sl:
+                        sl[vp] = len(nm)
+                        nm.append(vp)
+                if len(nm) > self.N:
+                    raise _lib.DsrgHipError('BatchedGraphMap: episode %d exceeds max_nodes=%d' % (i, self.N))
+            cur[i] = sl[ob['viewpoint']]             # (an ended episode repeats its last observation: all ids are known)
             ncand[i] = len(cc)
-            cpos[i] = ob['position']
-            for j, c in enumerate(cc):
-                kpos[i, j] = c['position']
-            head[i], elev[i] = ob['heading'], ob['elevation']
             n_new[i] = len(nm)
+            cpos[i] = ob['position']
+            head[i], elev[i] = ob['heading'], ob['elevation']
+            for j, c in enumerate(cc):
+                cand[i, j] = sl[c['viewpointId']]
+                kpos[i, j] = c['position']
         dev = self.device
-        t = lambda a: torch.from_numpy(a).to(dev, non_blocking=True)
-        self._cur = {'cur': t(cur), 'ncand': t(ncand), 'cand': t(cand), 'cpos': t(cpos), 'kpos': t(kpos), 'head': t(head), 'elev': t(elev),
-                     'n_new': t(n_new), 'cur_np': cur, 'cand_np': cand, 'ncand_np': ncand}
+        ibd, fbd = torch.from_numpy(ib).to(dev), torch.from_numpy(fb).to(dev)
+        self._cur = {'cur': ibd[:B], 'ncand': ibd[B:2 * B], 'n_new': ibd[2 * B:3 * B], 'cand': ibd[3 * B:], 'cpos': fbd[:3 * B],
+                     'head': fbd[3 * B:4 * B], 'elev': fbd[4 * B:5 * B], 'kpos': fbd[5 * B:], 'cur_np': cur, 'cand_np': cand,
+                     'ncand_np': ncand}
         return self._cur
 
     def _observe(self, obs, graph_active, step_active, step_value):
@@ -95,8 +89,8 @@ class BatchedGraphMap:
         p = self._pack(obs, ga)
         for i in np.nonzero(ga)[0]:
             self.host_visited[i].add(int(p['cur_np'][i]))
-        u8 = lambda a: torch.from_numpy(np.asarray(a, np.uint8)).to(self.device)
-        gad, sad = u8(ga), u8(step_active)
+        m = torch.from_numpy(np.concatenate([ga, np.asarray(step_active, bool)]).astype(np.uint8)).to(self.device)
+        gad, sad = m[:self.B], m[self.B:]
         _lib.check(_lib.load().dsrg_graph_observe(C.byref(self._state), K._p(gad), K._p(sad), K._p(p['cur']), K._p(p['n_new']), K._p(p['ncand']),
                                                   K._p(p['cand']), K._p(p['cpos']), K._p(p['kpos']), self.C, int(step_value), self.B,
                                                   K._stream()), 'dsrg_graph_observe')
@@ -121,8 +115,8 @@ class BatchedGraphMap:
         if self._cur is None:
             raise _lib.DsrgHipError('BatchedGraphMap: reset() first')
         p = self._cur
-        u8 = lambda a: torch.from_numpy(np.asarray(a, np.uint8)).to(self.device)
-        none, sa = u8([False] * self.B), u8(~np.asarray(ended, bool))
+        m = torch.from_numpy(np.concatenate([np.zeros(self.B, bool), ~np.asarray(ended, bool)]).astype(np.uint8)).to(self.device)
+        none, sa = m[:self.B], m[self.B:]
         _lib.check(_lib.load().dsrg_graph_observe(C.byref(self._state), K._p(none), K._p(sa), K._p(p['cur']), K._p(p['n_new']), K._p(p['ncand']),
                                                   K._p(p['cand']), K._p(p['cpos']), K._p(p['kpos']), self.C, int(t) + 1, self.B, K._stream()),
                    'dsrg_graph_observe')
