@@ -51,3 +51,64 @@ def test_batched_graphmap_matches_reference_fixture(dtype):
         if nobs is not None:
             gm.observe(nobs, nended)
     replay(make, step)
+
+
+def test_rollout_with_device_graphmap_matches_oracle_rollout():
+    """The pieces compose: language -> per step [panorama -> device graph map -> navigation -> action tail] on the HIP side
+    (fp32) against the CPU oracle model fed by the restated reference GraphMap + builders, on the same synthetic walks.
+    Fused logits within 1e-3, same greedy actions, same stop probabilities."""
+    from dsrg_amd import synth, functional as Fn
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.graphmap import BatchedGraphMap
+    from dsrg_amd.vilmodel import GlocalTextPathNavCMT
+    from oracle import dsrg_oracle, agent_oracle as AO
+    torch.set_num_threads(16)
+    B, T, V, L, seed = 4, 4, 36, 40, 21
+    cfg = DSRGConfig()
+    sd = common.synth_sd('r2r_c1')
+    m = GlocalTextPathNavCMT.from_pretrained(None, config=cfg, state_dict=dict(sd), compute_dtype=torch.float32).cuda().eval()
+    obs, ended = synth.episode_walks(B, T, seed)
+    lb = synth.language_batch(B, L, seed)
+    t_cpu = dsrg_oracle.forward(sd, cfg, 'language', common.to_t(lb))
+    with torch.no_grad():
+        t_gpu = m('language', common.to_t(lb, 'cuda'))
+    gmaps = [AO.GraphMap(ob['viewpoint']) for ob in obs[0]]
+    for i, ob in enumerate(obs[0]):
+        gmaps[i].update_graph(ob)
+    gm = BatchedGraphMap(B, 768, 'cuda', dtype=torch.float32, max_nodes=48, max_cand=8)
+    gm.reset(obs[0])
+    mem_c = mem_g = None
+    for t in range(T):
+        cand = [[c['viewpointId'] for c in ob['candidate']] for ob in obs[t]]
+        pb = synth.panorama_batch(B, V, 3, seed + t)
+        pb['nav_types'] = np.stack([np.asarray([1] * len(c) + [0] * (V - len(c)), np.int64) for c in cand])
+        # ---- oracle side
+        AO.step_begin(gmaps, obs[t], t, ended[t])
+        pe, pm, pf = dsrg_oracle.forward(sd, cfg, 'panorama', common.to_t(pb))
+        AO.update_embeds(gmaps, obs[t], cand, pe.numpy(), pf.numpy(), ended[t])
+        nav = AO.nav_gmap_variable(obs[t], gmaps, None if mem_c is None else mem_c.numpy())
+        nav.update(AO.nav_vp_variable(obs[t], gmaps, pe.numpy(), cand, [V] * B, pb['nav_types'], None if mem_c is None else mem_c.numpy()))
+        nb = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in nav.items()}
+        nb.update(txt_embeds=t_cpu, txt_masks=torch.from_numpy(lb['txt_masks']), vp_obj_masks=None)
+        o_c = dsrg_oracle.forward(sd, cfg, 'navigation', nb)
+        mem_c = o_c['cls_embeds']
+        # ---- HIP side
+        with torch.no_grad():
+            gm.begin_step(obs[t], t, ended[t])
+            pe_g, pm_g, pf_g = m('panorama', common.to_t(pb, 'cuda'))
+            gm.update_embeds(pe_g, pf_g, ended[t])
+            ng = gm.nav_inputs(pe_g, torch.from_numpy(pb['nav_types']).cuda(), torch.full((B,), V, device='cuda'), mem_g)
+            ng.update(txt_embeds=t_gpu, txt_masks=torch.from_numpy(lb['txt_masks']).cuda())
+            o_g = m('navigation', ng)
+            mem_g = o_g['cls_embeds']
+            tail = Fn.action_tail(o_g['fused_logits'])
+        fc, fg = o_c['fused_logits'].numpy(), o_g['fused_logits'].cpu().numpy()
+        fin = np.isfinite(fc)
+        assert (np.isfinite(fg) == fin).all() and np.abs(fg[fin] - fc[fin]).max() <= 1e-3, (t, np.abs(fg[fin] - fc[fin]).max())
+        assert np.array_equal(tail['argmax'].cpu().numpy(), fc.argmax(1))
+        assert np.abs(tail['stop_prob'].cpu().numpy() - torch.softmax(o_c['fused_logits'], 1)[:, 0].numpy()).max() <= 1e-4
+        if t + 1 < T:
+            for i, ob in enumerate(obs[t + 1]):
+                if not ended[t + 1][i]:
+                    gmaps[i].update_graph(ob)
+            gm.observe(obs[t + 1], ended[t + 1])
