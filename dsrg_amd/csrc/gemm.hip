@@ -9,6 +9,7 @@
 // lane's 4 accumulator registers are 4 CONSECUTIVE output columns n of one row m: the epilogue then
 // reads bias/residual and writes C with 8/16-byte vector accesses.
 #include <stdlib.h>
+#include <type_traits>
 #ifndef DSRG_ABLATE
 #define DSRG_ABLATE 0   // diagnostic builds: 1 = no LDS-DMA in the K loop, 2 = no fragment reads / MFMA
 #endif
@@ -28,9 +29,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+template <bool SHORT_GELU>
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
-    case DSRG_ACT_GELU: return gelu_erf(v);
+    case DSRG_ACT_GELU: return SHORT_GELU ? gelu_erf_short(v) : gelu_erf(v);
     case DSRG_ACT_RELU: return fmaxf(v, 0.0f);
     case DSRG_ACT_TANH: return tanhf(v);
     default: return v;
@@ -83,35 +85,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   // One wave-instruction moves 8 tile rows (64 lanes x 16 B = 1 KiB, lane-linear in LDS); the XOR swizzle is
   // applied to the per-lane SOURCE chunk, the LDS image stays linear (row*128 + pos*16), and the fragment reads
   // use the same involution.  Rows past M / N are clamped to the last valid row (their results are never stored).
+  // Addresses are scalar base (A or W, advanced along K in SGPRs) + a per-lane 32-bit byte offset that never changes,
+  // so one DMA costs three scalar instructions and no vector ALU work.
   constexpr int TR = BM + BN;           // tile rows per stage (A rows then W rows)
   constexpr int LPS = TR / 32;          // LDS-DMA instructions per wave per stage
-  const T* src[LPS];
+  constexpr int LPA = BM / 32;          // ... of which the first LPA fetch A rows
+  unsigned voff[LPS];
 #pragma unroll
   for (int i = 0; i < LPS; ++i) {
-    const int rb = i * 4 + wave;                       // 8-row block of the stage
-    const int row = rb * 8 + (lane >> 3);
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);  // row of the stage
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    if (rb * 8 < BM) {
-      const int m = min(m0 + row, M - 1);
-      src[i] = A + (size_t)m * P.lda + chunk * PER16;
-    } else {
-      const int n = min(n0 + row - BM, N - 1);
-      src[i] = W + (size_t)n * P.ldw + chunk * PER16;
-    }
+    if (i < LPA) voff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(P.lda * (int)sizeof(T)) + chunk * 16;
+    else voff[i] = (unsigned)min(n0 + row - BM, N - 1) * (unsigned)(P.ldw * (int)sizeof(T)) + chunk * 16;
   }
   // The DMA is issued from inline asm on purpose: hipcc does not count asm memory operations, so it cannot
   // drain the ring with a vmcnt(0) in front of the fragment reads (it does for the builtin form); completion is
   // tracked by the counted s_waitcnt below.  M0 (LDS destination base) is written in the statement that uses it.
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+  auto issue1 = [&](int i, int stage, int k0) {
+    const unsigned dst = ldsw + stage * TILE_BYTES + i * 4096;
+    const T* base = (i < LPA ? A : W) + k0;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[i]), "s"(base), "s"(dst) : "memory");
+  };
   auto issue = [&](int stage, int k0) {
 #pragma unroll
-    for (int i = 0; i < LPS; ++i) {
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * TILE_BYTES + (i * 4 + wave) * 1024);
-      const T* g = src[i] + k0;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-    }
+    for (int i = 0; i < LPS; ++i) issue1(i, stage, k0);
   };
 
   f32x4 acc[MT][NT];
@@ -122,52 +122,117 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 
   const int nk = K / BK;
   constexpr int D = NST - 1;                 // prefetch distance in K-steps
+  // One fragment read (index r < MT+NT: A-fragment r, or W-fragment r-MT) of half K-step `kk` of a stage.
+  auto rd1 = [&](uint4 (&fa)[MT], uint4 (&fw)[NT], int r, int stage, int kk) {
+    const char* sa = smem + stage * TILE_BYTES;
+    const int chunk = q + 4 * kk;
+    if (r < MT) fa[r] = *reinterpret_cast<const uint4*>(sa + swz(wm * WM + r * 16 + r16, chunk));
+    else fw[r - MT] = *reinterpret_cast<const uint4*>(sa + BM * ROWB + swz(wn * WN + (r - MT) * 16 + r16, chunk));
+  };
+  // The bf16 MFMA is an asm statement with the accumulator tied to an AGPR: (1) the register allocator otherwise
+  // shuttles the 128-192 accumulator registers of the 256-row tiles between the two register files once the
+  // fragments are double-buffered; (2) volatile statements keep the order written below, which IS the schedule.
+  auto mfma1 = [&](const uint4& fa, const uint4& fw, f32x4& c) {
+    if constexpr (sizeof(T) == 2) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                   : "+a"(c) : "v"(__builtin_bit_cast(u32x4, fw)), "v"(__builtin_bit_cast(u32x4, fa)));
+    } else {
+      const float* pw = reinterpret_cast<const float*>(&fw);
+      const float* pa = reinterpret_cast<const float*>(&fa);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[e], pa[e], c, 0, 0, 0);
+    }
+  };
+  // Half a K-step: the MT*NT MFMAs on (fa, fw), with the MT+NT fragment reads of the NEXT half step (into na, nw) and
+  // the refill DMAs [P0, P1) of a stage spread evenly between them - a workgroup that is alone on its CU (the 256-row
+  // tiles) has no other wave to hide LDS latency or DMA issue behind, so the overlap has to be inside the wave.  A DMA
+  // piece holds the issuing wave for 60-180 cycles while the CU's one address path (64 B/clk: 16 clk per 1 KiB piece,
+  // shared by the four waves) works through the queue, hence at most one piece per ~4 MFMAs.
+  auto half = [&](const uint4 (&fa)[MT], const uint4 (&fw)[NT], uint4 (&na)[MT], uint4 (&nw)[NT], int rstage, int rkk,
+                  auto p0_tag, auto p1_tag, int dstage, int dk0) {
+    constexpr int P0 = decltype(p0_tag)::value, P1 = decltype(p1_tag)::value, NP = P1 - P0;
+    constexpr int NM = MT * NT, R = MT + NT;
+    int r = 0, d = 0;
+#pragma unroll
+    for (int idx = 0; idx < NM; ++idx) {
+#if DSRG_ABLATE != 2
+      mfma1(fa[idx / NT], fw[idx % NT], acc[idx / NT][idx % NT]);
+#endif
+#if DSRG_ABLATE != 1
+      if (d < NP && d * NM <= idx * NP) { issue1(P0 + d, dstage, dk0); ++d; }
+#endif
+      if (r < R && r * NM <= idx * R) { rd1(na, nw, r, rstage, rkk); ++r; }
+    }
+#pragma unroll
+    for (; r < R; ++r) rd1(na, nw, r, rstage, rkk);
+#if DSRG_ABLATE != 1
+#pragma unroll
+    for (; d < NP; ++d) issue1(P0 + d, dstage, dk0);
+#endif
+  };
+  // stage `st` has landed once all but the DMAs of the (up to D-1) younger stages are done; wait + barrier are one
+  // statement with a memory clobber (no LDS access may move across it).  After the barrier every wave has also
+  // finished READING stage st-1 (its fragment loads are waited for first), so that buffer is refilled right away.
+  auto land = [&](int st) {
+    const int younger = min(D - 1, nk - 1 - st);
+    if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  // The refill of stage s goes into the buffer of stage s-1-D, free from the barrier in the middle of K-step s-1-D on.
+  // With D >= 2 its pieces are split over the second half of that K-step ([0,H)) and the first half of the next one
+  // ([H,LPS)); a 2-deep ring needs the stage one half step later, so all of them go into the second half.
+  constexpr int H = D >= 2 ? LPS / 2 : LPS;
+  using Z = std::integral_constant<int, 0>;
+  using PH = std::integral_constant<int, H>;
+  using PL = std::integral_constant<int, LPS>;
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nk) issue(d, d * BK);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once all but the DMAs of the (up to D-1) younger stages are done
-    // (wait + barrier in one statement with a memory clobber: no LDS access may move across it)
-    const int younger = min(D - 1, nk - 1 - kt);
-    if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
-    else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    // everyone's stage-kt DMAs landed and everyone is done reading stage kt-1: refill that buffer
+  uint4 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
+  land(0);
 #if DSRG_ABLATE != 1
-    if (kt + D < nk) issue(cur == 0 ? NST - 1 : cur - 1, (kt + D) * BK);
+  if (D < nk) {
+#pragma unroll
+    for (int i = 0; i < H; ++i) issue1(i, D, D * BK);
+  }
 #endif
-    const char* sa = smem + cur * TILE_BYTES;
-    const char* sw = sa + BM * ROWB;
+#pragma unroll
+  for (int r = 0; r < MT + NT; ++r) rd1(fa0, fw0, r, 0, 0);
+  // Straight-line phases (steady state, last refill, drain, last step) rather than one loop with branches: every
+  // control-flow merge inside the loop makes the register allocator copy the whole accumulator.
+  int cur = 0, prv = NST - 1, kt = 0;
+  for (; kt + 1 + D < nk; ++kt) {
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
+    half(fa0, fw0, fa1, fw1, cur, 1, PH{}, PL{}, prv, (kt + D) * BK);          // rest of stage kt+D
+    if (D >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
+    else if (D == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    half(fa1, fw1, fa0, fw0, nxt, 0, Z{}, PH{}, cur, (kt + 1 + D) * BK);        // start of stage kt+1+D
+    prv = cur; cur = nxt;
+  }
+  if (kt + D < nk && kt + 1 < nk) {                                              // K-step nk-1-D: the last refill ends here
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
+    half(fa0, fw0, fa1, fw1, cur, 1, PH{}, PL{}, prv, (kt + D) * BK);
+    land(kt + 1);
+    half(fa1, fw1, fa0, fw0, nxt, 0, Z{}, Z{}, 0, 0);
+    prv = cur; cur = nxt; ++kt;
+  }
+  for (; kt + 1 < nk; ++kt) {
+    const int nxt = cur == NST - 1 ? 0 : cur + 1;
+    half(fa0, fw0, fa1, fw1, cur, 1, Z{}, Z{}, 0, 0);
+    land(kt + 1);
+    half(fa1, fw1, fa0, fw0, nxt, 0, Z{}, Z{}, 0, 0);
+    cur = nxt;
+  }
+  half(fa0, fw0, fa1, fw1, cur, 1, Z{}, Z{}, 0, 0);
 #if DSRG_ABLATE != 2
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int chunk = q + 4 * kk;
-      uint4 fa[MT], fw[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(wm * WM + i * 16 + r16, chunk));
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const uint4*>(sw + swz(wn * WN + j * 16 + r16, chunk));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fw[j]),
-                __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, fa[i]), acc[i][j], 0, 0, 0);
-          } else {
-            const float* pw = reinterpret_cast<const float*>(&fw[j]);
-            const float* pa = reinterpret_cast<const float*>(&fa[i]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[e], pa[e], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
+  for (int idx = 0; idx < MT * NT; ++idx) mfma1(fa1[idx / NT], fw1[idx % NT], acc[idx / NT][idx % NT]);
 #endif
-    cur = cur == NST - 1 ? 0 : cur + 1;
-  }
+  // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the XDL-write -> VALU/LDS-read distance
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- epilogue.  A lane holds C[m][n..n+3] for 16 different rows per store, i.e. 32/64-byte row pieces: written
   // straight to HBM that pattern, not the K loop, bounds these mid-size GEMMs.  The raw accumulators therefore go
@@ -179,48 +244,58 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   OutT* __restrict__ C = reinterpret_cast<OutT*>(P.C);
   const int act = args.act;
   constexpr int CPR = BN / 4;                       // 16-B chunks per image row
+  // Tiles whose fp32 image does not fit the ring (256x192: 192 KiB) leave in two passes, one per wave row.
+  constexpr int EPASS = (BM * BN * 4 > 160 * 1024) ? 2 : 1;
+  constexpr int EROWS = BM / EPASS;
+  static_assert(EPASS == 1 || EROWS == WM, "two-pass epilogue splits the tile by wave row");
+  static_assert(EPASS == 1 || EROWS * BN * 4 <= NST * TILE_BYTES, "a half image must fit the ring");
   float* cimg = reinterpret_cast<float*>(smem);
-  __syncthreads();                                  // every wave is done reading the last stage
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = wm * WM + i * 16 + r16;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int chunk = (wn * WN + j * 16) / 4 + q;
-      *reinterpret_cast<f32x4*>(cimg + row * BN + ((chunk ^ (row & 7)) << 2)) = acc[i][j];
-    }
-  }
-  __syncthreads();
   const int oc = tid % CPR, orow0 = tid / CPR;      // this thread's chunk (fixed) and first row
-  constexpr int RPP = 256 / CPR;                    // rows per pass
+  constexpr int RPP = 256 / CPR;                    // rows per pass (threads past RPP*CPR idle when 256 % CPR != 0)
   const int n = n0 + oc * 4;
-  if (n < N) {
-    const bool vec = (n + 3 < N) && ((P.ldc & 3) == 0) && (Rp == nullptr || (P.ldr & 3) == 0);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
+  const bool vec = (n + 3 < N) && ((P.ldc & 3) == 0) && (Rp == nullptr || (P.ldr & 3) == 0);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && n < N) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < N) bv[e] = bias[n + e];
-    }
-#pragma unroll 4
-    for (int r = orow0; r < BM; r += RPP) {
-      const int m = m0 + r;
-      if (m >= M) break;
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((oc ^ (r & 7)) << 2));
-      float v[4];
+    for (int e = 0; e < 4; ++e)
+      if (n + e < N) bv[e] = bias[n + e];
+  }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(a4[e] + bv[e], act);
-      if (vec) {
-        if (Rp) {
-          const float4 rr = ld4(Rp + (size_t)m * P.ldr + n);
-          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+  for (int ep = 0; ep < EPASS; ++ep) {
+    __syncthreads();                                // every wave is done reading the last stage / the previous image
+    if (EPASS == 1 || wm == ep) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = (EPASS == 1 ? wm * WM : 0) + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int chunk = (wn * WN + j * 16) / 4 + q;
+          *reinterpret_cast<f32x4*>(cimg + row * BN + ((chunk ^ (row & 7)) << 2)) = acc[i][j];
         }
-        st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-      } else {
-        for (int e = 0; e < 4 && n + e < N; ++e) {
-          float x = v[e];
-          if (Rp) x += Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
-          Elem<OutT>::st(C + (size_t)m * P.ldc + n + e, x);
+      }
+    }
+    __syncthreads();
+    if (n < N && orow0 < RPP) {
+#pragma unroll 4
+      for (int r = orow0; r < EROWS; r += RPP) {
+        const int m = m0 + ep * EROWS + r;
+        if (m >= M) break;
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((oc ^ (r & 7)) << 2));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<sizeof(OutT) == 2>(a4[e] + bv[e], act);
+        if (vec) {
+          if (Rp) {
+            const float4 rr = ld4(Rp + (size_t)m * P.ldr + n);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+          }
+          st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+          for (int e = 0; e < 4 && n + e < N; ++e) {
+            float x = v[e];
+            if (Rp) x += Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
+            Elem<OutT>::st(C + (size_t)m * P.ldc + n + e, x);
+          }
         }
       }
     }
@@ -230,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 template <typename T, typename OutT, int BM, int BN, int NST>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
-  constexpr int smem = ring > cimg ? ring : cimg;
+  constexpr int smem = (ring > cimg || cimg > 160 * 1024) ? ring : cimg;     // oversize images leave in two passes
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, BM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -244,7 +319,8 @@ int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
 int g_nst_override = 0;
 
 // tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
-int plan_tiles(GemmArgs& a, int& bm, int& bn) {
+int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
+  (void)big_ok;
   auto count = [&](int m, int n) {
     int tot = 0;
     for (int i = 0; i < a.nprob; ++i) {
@@ -257,15 +333,25 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn) {
   int maxM = 0;
   for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
   static const char* force = getenv("DSRG_GEMM_TILE");     // tuning aid: "128x128" | "64x128" | "64x64"
-  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))
-    return count(bm, bn);
+  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && ((bm == 256 && (bn == 128 || bn == 192)) || ((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))))
+#ifdef DSRG_GEMM_BIG_TILES
+    if (big_ok || bm < 256) return count(bm, bn);
+#else
+    if (bm < 256) return count(bm, bn);
+#endif
   // Measured on MI355X (tools/bench_gemm.py): with a 2-deep ring every tile keeps >= 2 workgroups per CU, and the
   // mid-size GEMMs of a nav-step (174..1400 tiles) are bound by per-workgroup latency, not by the MFMA rate, so the
   // smallest tile that still gives >= 2 workgroups per CU wins; 128x128 only pays on >= ~4 rounds of tiles.
   int minK = 1 << 30;
   for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
   if (maxM > 64 && minK >= 512 && count(128, 128) >= 1000) { bm = 128; bn = 128; }
-  else if (maxM > 64 && count(64, 128) >= 512) { bm = 64; bn = 128; }
+  else if (maxM > 64 && count(64, 128) >= 512) {
+    // 64x128 keeps 3 workgroups per CU (768 slots): a tile count just above that leaves a near-empty second round,
+    // which one round of 128x128 tiles (2 per CU) beats (panorama FFN-in, 864 tiles: 29.4 -> 23.8 us)
+    const int t = count(64, 128);
+    if (t > 768 && t <= 960 && minK >= 512 && count(128, 128) <= 512) { bm = 128; bn = 128; }
+    else { bm = 64; bn = 128; }
+  }
   else { bm = 64; bn = 64; }
   return count(bm, bn);
 }
@@ -273,7 +359,7 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn) {
 template <typename T, typename OutT>
 int dispatch_tile(GemmArgs& a, hipStream_t s) {
   int bm, bn;
-  const int tiles = plan_tiles(a, bm, bn);
+  const int tiles = plan_tiles(a, bm, bn, sizeof(T) == 2);
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
   a.gm = gm_env ? atoi(gm_env) : 4;
   if (a.gm < 1) a.gm = 1;
@@ -286,6 +372,12 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
     if (minK >= 1024) nst = 3;
   }
+#ifdef DSRG_GEMM_BIG_TILES   // experiment: 256-row tiles, one workgroup per CU; reached only through DSRG_GEMM_TILE
+  if constexpr (sizeof(T) == 2) {
+    if (bm == 256 && bn == 192) return launch<T, OutT, 256, 192, 2>(a, tiles, s);
+    if (bm == 256) return launch<T, OutT, 256, 128, 3>(a, tiles, s);
+  }
+#endif
   if (bm == 128) {
     if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
     return launch<T, OutT, 128, 128, 2>(a, tiles, s);
@@ -339,12 +431,11 @@ extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, 
 
 extern "C" int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int* bm, int* bn, int* ntiles) {
   DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS && bm && bn && ntiles, "dsrg_gemm_nt_plan: bad arguments");
-  (void)dtype;
   GemmArgs a;
   a.nprob = 0;
   for (int i = 0; i < nproblems; ++i)
     if (problems[i].M > 0 && problems[i].N > 0) a.p[a.nprob++] = problems[i];
   *bm = *bn = *ntiles = 0;
-  if (a.nprob) *ntiles = plan_tiles(a, *bm, *bn);
+  if (a.nprob) *ntiles = plan_tiles(a, *bm, *bn, dtype == DSRG_BF16);
   return DSRG_OK;
 }

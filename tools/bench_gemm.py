@@ -57,7 +57,27 @@ def main():
         e1.record(); e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (rep * inner)
         fl = sum(2.0 * M * N * Kd for (M, N, Kd) in probs)
-        print('%-44s %8.1f us  %7.1f TFLOP/s' % (name, us, fl / us / 1e6), flush=True)
+        line = '%-44s %8.1f us  %7.1f TFLOP/s' % (name, us, fl / us / 1e6)
+        if '--blas' in sys.argv:     # yardstick only: the vendor library's plain GEMM (no epilogue) on the same operands
+            ys = [torch.empty(x.shape[0], w.shape[0], device='cuda', dtype=dt) for (x, w, _, _) in ps]
+            def blas():
+                for (x, w, _, _), y in zip(ps, ys):
+                    torch.mm(x, w.t(), out=y)
+            for _ in range(3):
+                blas()
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                for _ in range(inner):
+                    blas()
+            g2.replay(); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(rep):
+                g2.replay()
+            e1.record(); e1.synchronize()
+            us2 = e0.elapsed_time(e1) * 1e3 / (rep * inner)
+            line += '   | vendor GEMM (no epilogue) %8.1f us %7.1f TFLOP/s' % (us2, fl / us2 / 1e6)
+        print(line, flush=True)
 
 if __name__ == '__main__':
     main()
