@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   const int act = args.act;
   constexpr int CPR = BN / 4;                       // 16-B chunks per image row
   // Tiles whose fp32 image does not fit the ring (256x192: 192 KiB) leave in two passes, one per wave row.
-  constexpr int EPASS = (BM * BN * 4 > 160 * 1024) ? 2 : 1;
+  constexpr int EPASS = (BM * BN * 4 > NST * TILE_BYTES) ? 2 : 1;
   constexpr int EROWS = BM / EPASS;
   static_assert(EPASS == 1 || EROWS == WM, "two-pass epilogue splits the tile by wave row");
   static_assert(EPASS == 1 || EROWS * BN * 4 <= NST * TILE_BYTES, "a half image must fit the ring");
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 template <typename T, typename OutT, int BM, int BN, int NST>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
-  constexpr int smem = (ring > cimg || cimg > 160 * 1024) ? ring : cimg;     // oversize images leave in two passes
+  constexpr int smem = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, BM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -320,7 +320,6 @@ int g_nst_override = 0;
 
 // tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
 int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
-  (void)big_ok;
   auto count = [&](int m, int n) {
     int tot = 0;
     for (int i = 0; i < a.nprob; ++i) {
@@ -333,12 +332,14 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
   int maxM = 0;
   for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
   static const char* force = getenv("DSRG_GEMM_TILE");     // tuning aid: "128x128" | "64x128" | "64x64"
-  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && ((bm == 256 && (bn == 128 || bn == 192)) || ((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))))
-#ifdef DSRG_GEMM_BIG_TILES
-    if (big_ok || bm < 256) return count(bm, bn);
-#else
-    if (bm < 256) return count(bm, bn);
+  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && ((bm == 256 && (bn == 128 || bn == 192)) || (bm == 128 && bn == 192) || ((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))))
+{
+    bool ok = big_ok || !(bm == 256 || bn == 192);      // the wide tiles exist for bf16 only
+#ifndef DSRG_GEMM_BIG_TILES
+    if (bm == 256) ok = false;
 #endif
+    if (ok) return count(bm, bn);
+  }
   // Measured on MI355X (tools/bench_gemm.py): with a 2-deep ring every tile keeps >= 2 workgroups per CU, and the
   // mid-size GEMMs of a nav-step (174..1400 tiles) are bound by per-workgroup latency, not by the MFMA rate, so the
   // smallest tile that still gives >= 2 workgroups per CU wins; 128x128 only pays on >= ~4 rounds of tiles.
@@ -378,6 +379,9 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
     if (bm == 256) return launch<T, OutT, 256, 128, 3>(a, tiles, s);
   }
 #endif
+  if constexpr (sizeof(T) == 2) {
+    if (bm == 128 && bn == 192) return launch<T, OutT, 128, 192, 2>(a, tiles, s);
+  }
   if (bm == 128) {
     if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
     return launch<T, OutT, 128, 128, 2>(a, tiles, s);

@@ -605,13 +605,15 @@ class GlocalTextPathNavCMT(nn.Module):
         txt = txt_embeds.to(cd)
         txt = txt if txt.is_contiguous() else txt.contiguous()
         tm = txt_masks.contiguous()
+        # the two token-embedding launches are latency-bound and independent: side by side on two streams
+        vj = self._fork(lambda: Fn.embed_ln(B * Vp, H, cd, dev, base=vp_img_embeds.to(cd).reshape(B * Vp, H),
+                                            feat=vp_pos_fts.float().reshape(B * Vp, -1).contiguous(), Wf=W['vp.pos.w'],
+                                            bf=W['vp.pos.b'], lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H))
         g = Fn.embed_ln(B * G, H, cd, dev, base=gmap_img_embeds.to(cd).reshape(B * G, H),
                         feat=gmap_pos_fts.float().reshape(B * G, -1).contiguous(), Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'],
                         lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']), E1=W['gmap.step'],
                         idx1=gmap_step_ids.reshape(-1)).view(B, G, H)
-        v = Fn.embed_ln(B * Vp, H, cd, dev, base=vp_img_embeds.to(cd).reshape(B * Vp, H),
-                        feat=vp_pos_fts.float().reshape(B * Vp, -1).contiguous(), Wf=W['vp.pos.w'], bf=W['vp.pos.b'],
-                        lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, Vp, H)
+        v = vj()
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
         # two streams pay when the branches are of similar size (R2R: 20 vs 38 tokens); with one much longer branch
