@@ -44,6 +44,19 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// non-temporal forms (the GEMM's C tiles are read next by another kernel on other XCDs: keep them out of the way of A/W in L2)
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+}
+__device__ __forceinline__ void st4_nt(bf16_t* p, float4 v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  u2 u;
+  u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+  u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+  __builtin_nontemporal_store(u, reinterpret_cast<u2*>(p));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

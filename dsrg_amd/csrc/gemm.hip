@@ -25,6 +25,8 @@ struct GemmArgs {
   int nprob;
   int act;
   int gm;          // M-tiles per super-row of the tile walk
+  int pw[DSRG_MAX_GROUPS];   // N-tiles per panel of the tile walk (per problem)
+  int nt_store;    // 1: C leaves with non-temporal stores
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -66,11 +68,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   const int M = P.M, N = P.N, K = P.K;
   const int t = bid - args.tile_start[g];
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int GM = args.gm;
-  const int per_group = GM * tiles_n;
-  const int grp = t / per_group, in_grp = t - grp * per_group;
+  // Walk: N-panels of PW tiles (outermost), inside a panel super-rows of GM M-tiles, inside a super-row N, then M
+  // fastest.  The ~T/8 consecutive tiles one XCD runs then cover a compact (T/8/PW) x PW patch of the tile grid whose
+  // A rows + W rows fit that XCD's 4 MiB L2 (PW is chosen on the host for that), instead of a stripe that needs all of W.
+  const int GM = args.gm, PW = args.pw[g];
+  const int full = tiles_m * PW;                        // tiles in a full panel
+  const int pnl = t / full, in_pnl = t - pnl * full;
+  const int wn_p = min(PW, tiles_n - pnl * PW);         // width of this (possibly narrower, last) panel
+  const int per_group = GM * wn_p;
+  const int grp = in_pnl / per_group, in_grp = in_pnl - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);          // rows in this (possibly short) super-row
-  const int tm = grp * GM + in_grp % gm, tn = in_grp / gm;
+  const int tm = grp * GM + in_grp % gm, tn = pnl * PW + in_grp / gm;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x;
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
             const float4 rr = ld4(Rp + (size_t)m * P.ldr + n);
             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
           }
-          st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+          if (args.nt_store) st4_nt(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+          else st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
         } else {
           for (int e = 0; e < 4 && n + e < N; ++e) {
             float x = v[e];
@@ -364,6 +373,24 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
   a.gm = gm_env ? atoi(gm_env) : 4;
   if (a.gm < 1) a.gm = 1;
+  static const char* np_env = getenv("DSRG_GEMM_NP");      // tuning aid: force the number of N-panels (1 = stripes)
+  static const char* nt_env = getenv("DSRG_GEMM_NT");      // tuning aid: 0/1 non-temporal C stores
+  a.nt_store = nt_env ? atoi(nt_env) : 0;   // 3-9 % faster launch by launch (tools/bench_gemm.py), 0.2 % slower inside the step: the consumer finds C in L2 less often
+  const int per_xcd = (tiles + 7) / 8;
+  for (int i = 0; i < a.nprob; ++i) {
+    const int tm_ = (a.p[i].M + bm - 1) / bm, tn_ = (a.p[i].N + bn - 1) / bn;
+    int best_pw = tn_;
+    long best = -1;
+    for (int np = 1; np <= tn_ && np <= 8; ++np) {
+      if (np_env && np != atoi(np_env) && atoi(np_env) >= 1 && atoi(np_env) <= tn_) continue;
+      const int pw = (tn_ + np - 1) / np;
+      int mt = (per_xcd + pw - 1) / pw;
+      if (mt > tm_) mt = tm_;
+      const long rows = (long)mt * bm + (long)pw * bn;   // A rows + W rows an XCD's patch touches
+      if (best < 0 || rows < best) { best = rows; best_pw = pw; }
+    }
+    a.pw[i] = best_pw;
+  }
   // Ring depth: 2 keeps the most workgroups per CU and wins whenever a CU holds >= 2 tiles; with <= ~1.7 tiles per CU
   // and a long K loop (the FFN-out projections of the panorama / object encoders) a lone workgroup cannot cover the
   // L2 latency with one stage in flight, and a 3-deep ring is 17-30 % faster (tools/bench_gemm.py).
