@@ -161,8 +161,11 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+#ifndef ATTN_MFMA_MIN_WAVES
+#define ATTN_MFMA_MIN_WAVES 1
+#endif
 template <bool DROP>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnGroup grp) {
+__global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
