@@ -44,6 +44,11 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+__device__ __forceinline__ float4 raw4(float4 v) { return v; }
+__device__ __forceinline__ float4 raw4(uint2 u) {     // 4 packed bf16
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
 // non-temporal forms (the GEMM's C tiles are read next by another kernel on other XCDs: keep them out of the way of A/W in L2)
 __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   typedef float f4 __attribute__((ext_vector_type(4)));

@@ -15,6 +15,16 @@
 #endif
 #include "common.h"
 
+#ifdef DSRG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): per-workgroup s_memtime stamps of the tile's phases
+__device__ unsigned long long g_gemm_stamps[8192 * 5];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dsrg_debug_gemm_stamps(void* host_dst, int nbytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_stamps), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;  // bytes of K per LDS tile row
@@ -43,6 +53,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 template <typename T, typename OutT, int BM, int BN, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
+  GEMM_STAMP(0);
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int WM = BM / 2, WN = BN / 2;     // wave tile (2x2 waves)
@@ -88,6 +99,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 
   const T* __restrict__ A = reinterpret_cast<const T*>(P.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(P.W);
+
+  // ---- this thread's place in the epilogue (fixed 16-B column chunk, rows orow0 + k*RPP) and its bias values, loaded
+  // here so that their latency hides behind the first stage's
+  const float* __restrict__ bias = P.bias;
+  const T* __restrict__ Rp = reinterpret_cast<const T*>(P.residual);
+  constexpr int CW = sizeof(OutT) == 2 ? 8 : 4;     // output columns per thread = one 16-byte store (stamps: with 8-byte
+                                                    // bf16 stores the epilogue was store-issue-bound, ~7 B/clk per CU)
+  constexpr int CPR = BN / CW;                      // threads per image row
+  constexpr int RPP = 256 / CPR;                    // rows per pass (threads past RPP*CPR idle when 256 % CPR != 0)
+  const int oc = tid % CPR, orow0 = tid / CPR;
+  const int n = n0 + oc * CW;
+  const bool vec = (n + CW - 1 < N) && (P.ldc % CW == 0) && (Rp == nullptr || (P.ldr % CW == 0 && ((uintptr_t)Rp & 15) == 0));
+  float bv[CW];
+#pragma unroll
+  for (int e = 0; e < CW; ++e) bv[e] = 0.f;
+  if (bias && n < N) {
+    if (n + CW - 1 < N) {
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + n + 4 * h);
+        bv[4 * h] = b4.x; bv[4 * h + 1] = b4.y; bv[4 * h + 2] = b4.z; bv[4 * h + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < CW; ++e)
+        if (n + e < N) bv[e] = bias[n + e];
+    }
+  }
 
   // ---- staging: LDS-DMA (global_load_lds_dwordx4), NST-deep ring, counted vmcnt.
   // One wave-instruction moves 8 tile rows (64 lanes x 16 B = 1 KiB, lane-linear in LDS); the XOR swizzle is
@@ -200,6 +239,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
     if (d < nk) issue(d, d * BK);
   uint4 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
   land(0);
+  GEMM_STAMP(1);
 #if DSRG_ABLATE != 1
   if (D < nk) {
 #pragma unroll
@@ -239,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 #pragma unroll
   for (int idx = 0; idx < MT * NT; ++idx) mfma1(fa1[idx / NT], fw1[idx % NT], acc[idx / NT][idx % NT]);
 #endif
+  GEMM_STAMP(2);
   // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the XDL-write -> VALU/LDS-read distance
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -247,26 +288,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   // through LDS (fp32 [BM][BN] image over the drained ring, 16-B chunk index XOR (row & 7): conflict-free both ways)
   // and leave as whole rows: 32 consecutive lanes cover BN consecutive columns (256 B bf16 / 512 B f32 per row),
   // with bias, activation and the residual (read with the same coalescing) applied on the way out.
-  const float* __restrict__ bias = P.bias;
-  const T* __restrict__ Rp = reinterpret_cast<const T*>(P.residual);
   OutT* __restrict__ C = reinterpret_cast<OutT*>(P.C);
   const int act = args.act;
-  constexpr int CPR = BN / 4;                       // 16-B chunks per image row
   // Tiles whose fp32 image does not fit the ring (256x192: 192 KiB) leave in two passes, one per wave row.
   constexpr int EPASS = (BM * BN * 4 > NST * TILE_BYTES) ? 2 : 1;
   constexpr int EROWS = BM / EPASS;
   static_assert(EPASS == 1 || EROWS == WM, "two-pass epilogue splits the tile by wave row");
   static_assert(EPASS == 1 || EROWS * BN * 4 <= NST * TILE_BYTES, "a half image must fit the ring");
   float* cimg = reinterpret_cast<float*>(smem);
-  const int oc = tid % CPR, orow0 = tid / CPR;      // this thread's chunk (fixed) and first row
-  constexpr int RPP = 256 / CPR;                    // rows per pass (threads past RPP*CPR idle when 256 % CPR != 0)
-  const int n = n0 + oc * 4;
-  const bool vec = (n + 3 < N) && ((P.ldc & 3) == 0) && (Rp == nullptr || (P.ldr & 3) == 0);
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias && n < N) {
+  // The residual pieces of this thread's rows are fetched NOW, ahead of the two barriers and the image round trip
+  // (in-kernel stamps: the epilogue was 30-45 % of a tile's lifetime, a third of it exposed global-load latency).
+  constexpr int NPASS = (EROWS + RPP - 1) / RPP;
+  constexpr bool PRE_RES = EPASS == 1 && NPASS <= 16;
+  typedef typename std::conditional<CW == 8, uint4, typename std::conditional<sizeof(T) == 2, uint2, float4>::type>::type RawRes;
+  RawRes rres[PRE_RES ? NPASS : 1];
+  if (PRE_RES && Rp && vec && n < N && orow0 < RPP) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < N) bv[e] = bias[n + e];
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int r = orow0 + ps * RPP, m = m0 + r;
+      if (r < EROWS && m < M) rres[ps] = *reinterpret_cast<const RawRes*>(Rp + (size_t)m * P.ldr + n);
+    }
   }
 #pragma unroll
   for (int ep = 0; ep < EPASS; ++ep) {
@@ -284,23 +325,45 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
     }
     __syncthreads();
     if (n < N && orow0 < RPP) {
-#pragma unroll 4
-      for (int r = orow0; r < EROWS; r += RPP) {
-        const int m = m0 + ep * EROWS + r;
-        if (m >= M) break;
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((oc ^ (r & 7)) << 2));
-        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act<sizeof(OutT) == 2>(a4[e] + bv[e], act);
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int r = orow0 + ps * RPP;
+        const int m = m0 + ep * EROWS + r;
+        if (r >= EROWS || m >= M) break;
+        float v[CW];
+#pragma unroll
+        for (int h = 0; h < CW / 4; ++h) {
+          const int ch = oc * (CW / 4) + h;           // 4-float chunk of the image row
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((ch ^ (r & 7)) << 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * h + e] = apply_act<sizeof(OutT) == 2>(a4[e] + bv[4 * h + e], act);
+        }
         if (vec) {
           if (Rp) {
-            const float4 rr = ld4(Rp + (size_t)m * P.ldr + n);
-            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            RawRes raw;
+            if constexpr (PRE_RES) raw = rres[ps];
+            else raw = *reinterpret_cast<const RawRes*>(Rp + (size_t)m * P.ldr + n);
+            if constexpr (CW == 8) {
+              const float4 r0 = raw4(make_uint2(raw.x, raw.y)), r1 = raw4(make_uint2(raw.z, raw.w));
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            } else {
+              const float4 rr = raw4(raw);
+              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
           }
-          if (args.nt_store) st4_nt(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-          else st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+          if constexpr (CW == 8) {
+            uint4 u;
+            u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+            u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+            *reinterpret_cast<uint4*>(C + (size_t)m * P.ldc + n) = u;
+          } else {
+            if (args.nt_store) st4_nt(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+            else st4(C + (size_t)m * P.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
+          }
         } else {
-          for (int e = 0; e < 4 && n + e < N; ++e) {
+          for (int e = 0; e < CW && n + e < N; ++e) {
             float x = v[e];
             if (Rp) x += Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
             Elem<OutT>::st(C + (size_t)m * P.ldc + n + e, x);
@@ -309,6 +372,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
       }
     }
   }
+  GEMM_STAMP(3);
+#ifdef DSRG_GEMM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#endif
 }
 
 template <typename T, typename OutT, int BM, int BN, int NST>

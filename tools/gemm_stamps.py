@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-workgroup phase timeline of dsrg_gemm_nt from in-kernel s_memtime stamps (diagnostic build only):
+   tools/build_variant.sh stamps -DDSRG_GEMM_STAMPS
+   DSRG_HIP_LIB=dsrg_amd/csrc/variants/libdsrg_hip_stamps.so python3 tools/gemm_stamps.py
+Stamps: 0 kernel entry, 1 first stage landed, 2 K loop done, 3 epilogue done (shader clock, 100 MHz s_memtime ticks
+are NOT used: s_memtime counts shader cycles)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from dsrg_amd import kernels as K, _lib
+
+SHAPES = [
+    ('x.cq g+l N=768 K=768 f32+res', [(1280, 768, 768), (2432, 768, 768)], 0, True, True),
+    ('x.qkv g+l N=2304 K=768', [(1280, 2304, 768), (2432, 2304, 768)], 0, False, False),
+    ('x.ff1 g+l N=3072 K=768 gelu', [(1280, 3072, 768), (2432, 3072, 768)], 1, False, False),
+    ('x.ff2 g+l N=768 K=3072 f32+res', [(1280, 768, 3072), (2432, 768, 3072)], 0, True, True),
+    ('pano.ff1 M=2304 N=3072 K=768 gelu', [(2304, 3072, 768)], 1, False, False),
+]
+
+
+def main():
+    lib = _lib.load()
+    fn = lib.dsrg_debug_gemm_stamps
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    dt = torch.bfloat16
+    for name, probs, act, of32, res in SHAPES:
+        ps = []
+        for (M, N, Kd) in probs:
+            x = (torch.rand(M, Kd, device='cuda') * 2 - 1).to(dt)
+            w = ((torch.rand(N, Kd, device='cuda') * 2 - 1) * 0.05).to(dt)
+            b = torch.rand(N, device='cuda')
+            r = (torch.rand(M, N, device='cuda') * 2 - 1).to(dt) if res else None
+            ps.append((x, w, b, r))
+        outs = K.gemm(ps, act, of32)
+        for _ in range(5):
+            K.gemm(ps, act, of32, outs=outs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); K.gemm(ps, act, of32, outs=outs); e1.record(); e1.synchronize()
+        plan = K.gemm_plan(ps) if hasattr(K, 'gemm_plan') else None
+        buf = np.zeros(8192 * 5, np.uint64)
+        assert fn(buf.ctypes.data, buf.nbytes) == 0
+        st = buf.reshape(8192, 5)
+        n = int((st[:, 3] > 0).sum())
+        st = st[:n].astype(np.int64)
+        t00 = st[:, 0].min()
+        span = st[:, 3].max() - t00
+        ph = [st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]]
+        q = lambda a: '%6d %6d %6d' % tuple(np.percentile(a, [10, 50, 90]))
+        print('%-36s wgs %5d  event %.1f us  span %7d clk' % (name, n, e0.elapsed_time(e1) * 1e3, span))
+        print('    start-after-first [10/50/90%%]: %s   end-before-last: %s' % (q(st[:, 0] - t00), q(st[:, 3].max() - st[:, 3])))
+        print('    prologue %s | K loop %s | epilogue %s | total %s  (clk, 10/50/90%%)' % (q(ph[0]), q(ph[1]), q(ph[2]), q(st[:, 3] - st[:, 0])))
+        late = st[:, 0] - t00 > 0.3 * span
+        print('    workgroups starting after 30%% of the span: %d (%.0f%%)' % (late.sum(), 100.0 * late.mean()))
+
+
+if __name__ == '__main__':
+    main()
