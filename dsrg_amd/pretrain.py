@@ -193,6 +193,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     # ------------------------------------------------------------------ heads
     def _hw(self):
         """compute-dtype views of the head weights (differentiable; small)."""
+        plan = getattr(self, '_hwplan', None)
+        if plan is not None and plan[2] is self.bert._wplan_token():
+            return self._hw_resolve(plan)
         cd = self.bert.compute_dtype
         W = {}
         pk = Fn.WeightPacker()
@@ -208,7 +211,19 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             p = self.mlm_head.predictions
             lin('mlm.t', p.transform.dense); ln('mlm.ln', p.transform.LayerNorm)
             W['mlm.dec.w'], W['mlm.dec.b'] = c(p.decoder.weight), f(p.bias)
-        return pk.resolve(W)
+        self._hwplan = plan = (W, pk, self.bert._wplan_token())
+        self._hwres = None
+        return self._hw_resolve(plan)
+
+    def _hw_resolve(self, plan):
+        """one pack per parameter version and grad mode (see GlocalTextPathNavCMT._resolve_weights)"""
+        W0, pk, _ = plan
+        key = (torch.is_grad_enabled(), tuple(p._version for p in pk.srcs))
+        if self._hwres is not None and self._hwres[0] == key:
+            return self._hwres[1]
+        W = pk.resolve(dict(W0))
+        self._hwres = (key, W)
+        return W
 
     def _scores(self, W, key, x):
         """ClsPrediction -> [..] raw scores (Linear+ReLU in the GEMM epilogue, LN+Linear(H,1) tail kernel)."""

@@ -171,7 +171,7 @@ class GlocalTextPathNavCMT(nn.Module):
 
         self.init_weights()
         self._apply_freeze_flags()
-        self._wcache, self._kv_cache = None, None
+        self._wcache, self._kv_cache, self._wplan, self._wgrad, self._wtoken = None, None, None, None, object()
         self._side_stream, self.overlap_streams, self._fork_depth = None, True, 0
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '0') == '1'     # opt-in: global / local x-layers on two streams (+2 % at R2R shapes)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
@@ -223,7 +223,13 @@ class GlocalTextPathNavCMT(nn.Module):
         return model.eval()
 
     def invalidate_caches(self):
-        self._wcache, self._kv_cache = None, None
+        self._wcache, self._kv_cache, self._wplan, self._wgrad = None, None, None, None
+        self._wtoken = object()
+
+    def _wplan_token(self):
+        """changes whenever invalidate_caches() ran (device / dtype move, train()/eval(), load_state_dict): dependants
+        that keep their own pack plan (the pre-training heads) compare it"""
+        return self._wtoken
 
     def train(self, mode=True):
         self.invalidate_caches()
@@ -237,9 +243,12 @@ class GlocalTextPathNavCMT(nn.Module):
     def _weights(self):
         """Compute-dtype / packed views of the parameters.  Cached when autograd is off; rebuilt with
         differentiable ops (cat / to) when it is on, so gradients reach the fp32 master parameters."""
-        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        plan = self._wplan
+        grad = torch.is_grad_enabled() and (plan is None or plan[2])
         if not grad and self._wcache is not None:
             return self._wcache
+        if plan is not None:
+            return self._resolve_weights(plan, grad)
         cd = self.compute_dtype
         pk = Fn.WeightPacker()          # every cast / concat below is served by ONE multi-tensor copy (and one in backward)
         c = lambda t: pk.cast(t, cd)
@@ -319,8 +328,24 @@ class GlocalTextPathNavCMT(nn.Module):
                     lin(k + '.lff1', L.lang_inter.dense); lin(k + '.lff2', L.lang_output.dense); ln(k + '.lfln', L.lang_output.LayerNorm)
         packed('x.txtkv', kv)       # [2 branches * layers * (K,V) * 768, 768]
         self._head_weights(W, lin, ln, f)
-        pk.resolve(W)
-        if not grad:
+        # the walk over the module tree above costs ~3 ms: its result (placeholders + the packer's source list) is kept
+        self._wplan = plan = (W, pk, any(p.requires_grad for p in self.parameters()))
+        return self._resolve_weights(plan, torch.is_grad_enabled() and plan[2])
+
+    def _resolve_weights(self, plan, grad):
+        """Run the plan's one multi-tensor pack.  With autograd on, the packed (differentiable) dict is reused until a
+        parameter changes (every in-place update - optimizer.step, load_state_dict - bumps Tensor._version): the three
+        sub-model calls of a pre-training step, or the language / panorama / navigation calls of a rollout, share one
+        pack and one _PackFn node.  (Writing through `.data` bypasses the version counter: call invalidate_caches().)"""
+        W0, pk, _ = plan
+        if grad:
+            ver = tuple(p._version for p in pk.srcs)
+            if self._wgrad is not None and self._wgrad[0] == ver:
+                return self._wgrad[1]
+        W = pk.resolve(dict(W0))
+        if grad:
+            self._wgrad = (ver, W)
+        else:
             self._wcache = W
         return W
 
