@@ -32,6 +32,7 @@ for i in range(6):
     loss = model(batches[bench.PT_TASKS[i % 3]], bench.PT_TASKS[i % 3], compute_loss=True).mean()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print('forward: host %.1f ms/step, +%.1f ms to drain' % ((t1 - t) / 6 * 1e3, (t2 - t1) / 6 * 1e3))
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile(); pr.enable()
 for i in range(12): step(i)
 torch.cuda.synchronize()
