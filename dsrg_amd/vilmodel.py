@@ -246,7 +246,10 @@ class GlocalTextPathNavCMT(nn.Module):
         plan = self._wplan
         grad = torch.is_grad_enabled() and (plan is None or plan[2])
         if not grad and self._wcache is not None:
-            return self._wcache
+            # eval(): weights are frozen until the next train()/eval()/load_state_dict() (those invalidate); a no-grad
+            # forward of a model in train() mode may follow an optimizer.step(), so there the versions are compared
+            if not self.training or self._wcache_ver == tuple(p._version for p in plan[1].srcs):
+                return self._wcache
         if plan is not None:
             return self._resolve_weights(plan, grad)
         cd = self.compute_dtype
@@ -346,7 +349,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if grad:
             self._wgrad = (ver, W)
         else:
-            self._wcache = W
+            self._wcache, self._wcache_ver = W, tuple(p._version for p in pk.srcs)
         return W
 
     def _cls_head_weights(self, W, key, hd, lin, ln, f):

@@ -128,3 +128,31 @@ def test_finetune_gradients_match_oracle_autograd(tag, reverie, dtype):
         assert err <= (2e-3 if fp32 else 2e-1), (k, err)
     assert len(worst) >= 12
     print(tag, dtype, 'grad rel-to-max', {'.'.join(k.split('.')[-2:]): '%.1e' % v for k, v in worst.items()})
+
+
+def test_weight_caches_follow_parameter_updates():
+    """The packed compute-dtype weights are cached; an in-place parameter update (optimizer.step) must be seen by the
+    next forward both with autograd on (version-keyed pack) and in a no-grad forward of a model left in train() mode."""
+    from dsrg_amd import synth
+    m = _model('r2r_c1', False, torch.float32).train()
+    for mod in m.modules():                       # dropout off: outputs comparable
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.config.hidden_dropout_prob = m.config.attention_probs_dropout_prob = 0.0
+    lb = common.to_t(synth.language_batch(4, 24, 5, min_len=10), 'cuda')
+    with torch.no_grad():
+        a = m('language', lb).clone()
+        assert torch.equal(a, m('language', lb))
+    x = m('language', lb)                         # autograd on
+    assert torch.allclose(x, a, atol=1e-5)
+    w1 = m._weights()
+    assert m._weights() is w1                     # one pack per parameter version
+    x.float().pow(2).mean().backward()
+    opt = torch.optim.SGD([p for p in m.parameters() if p.grad is not None], lr=0.5)
+    opt.step()
+    assert m._weights() is not w1
+    y = m('language', lb)
+    assert (y - x).abs().max() > 1e-4
+    with torch.no_grad():
+        z = m('language', lb)
+    assert torch.allclose(z, y, atol=1e-5) and (z - a).abs().max() > 1e-4
