@@ -226,7 +226,7 @@ def pretrain_main(a, dtype, dev, rank, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert all(torch.isfinite(v) for v in last.values()), 'non-finite pre-training loss'
@@ -292,10 +292,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the DSRG hot path has no CPU fallback')
+    # rehearsal aid (one-GPU box): DSRG_BENCH_BACKEND=gloo runs the N ranks on the visible device(s) round-robin
+    backend = os.environ.get('DSRG_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
 
     if a.config == 'c4':
@@ -329,7 +336,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fused = runner.out['fused_logits']
