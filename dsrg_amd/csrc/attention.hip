@@ -161,11 +161,18 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+#ifdef DSRG_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py)
+__device__ unsigned long long g_attn_stamps[16384 * 4];
+#define ATTN_STAMP(i) do { if (threadIdx.x == 0) { const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg < 16384) g_attn_stamps[wg * 4 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
 #ifndef ATTN_MFMA_MIN_WAVES
 #define ATTN_MFMA_MIN_WAVES 1
 #endif
 template <bool DROP>
 __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
+  ATTN_STAMP(0);
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
       }
     }
     __syncthreads();
+    ATTN_STAMP(1);
     if (!active) continue;
 
     // ---- S^T tiles
@@ -321,6 +329,7 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
       }
     }
   }
+  ATTN_STAMP(2);
   if (!active) return;
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
       st4(Op + (size_t)qrow * a.o_rs + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
     if (a.lse && g == 0) a.lse[((size_t)b * a.NH + h) * a.Nq + qrow] = m_run + logf(l_run);
   }
+  ATTN_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -566,6 +576,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 }
 
 }  // namespace
+
+#ifdef DSRG_ATTN_STAMPS
+extern "C" int dsrg_debug_attn_stamps(void* host_dst, int nbytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_attn_stamps), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, int nproblems, int mask_mode,
                                           const float* sprel_w, const float* sprel_b, int B, int NH, float scale, float p_drop,
