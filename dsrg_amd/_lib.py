@@ -11,7 +11,15 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
+
+
+class TransposeProblem(C.Structure):
+    _fields_ = [('inp', C.c_void_p), ('out', C.c_void_p), ('colsum', C.c_void_p), ('ld_in', C.c_int32), ('ld_out', C.c_int32),
+                ('R', C.c_int32), ('C', C.c_int32), ('Rp', C.c_int32), ('in_dtype', C.c_int32), ('out_dtype', C.c_int32), ('pad_', C.c_int32)]
+
+
+MAX_TRANSPOSES = 24
 
 
 class GemmProblem(C.Structure):
@@ -75,6 +83,7 @@ SIGNATURES = {
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_transpose_pad': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'dsrg_transpose_pad_grouped': (C.c_int, [C.POINTER(TransposeProblem), _I, _P]),
     'dsrg_colsum_acc': (C.c_int, [_P, _I, _P, _I, _I, _I, _P]),
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),
     'dsrg_act_bwd': (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),

@@ -36,6 +36,52 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const TI* __restrict
   }
 }
 
+// ---- grouped form: every operand transpose of one backward call in a single launch (1-D grid of 64x64 tiles)
+struct TransposeGroup {
+  dsrg_transpose_problem_t p[DSRG_MAX_TRANSPOSES];
+  int tile_start[DSRG_MAX_TRANSPOSES + 1];
+  int n;
+};
+__device__ __forceinline__ float ld_any(const void* p, size_t i, int dt) {
+  return dt == DSRG_F32 ? reinterpret_cast<const float*>(p)[i] : Elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p) + i);
+}
+__device__ __forceinline__ void st_any(void* p, size_t i, int dt, float v) {
+  if (dt == DSRG_F32) reinterpret_cast<float*>(p)[i] = v;
+  else Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p) + i, v);
+}
+__global__ __launch_bounds__(256) void transpose_pad_grouped_kernel(const TransposeGroup grp) {
+  __shared__ float tile[64][65];
+  __shared__ float part[4][64];
+  int g = 0;
+  for (int i = 1; i < grp.n; ++i)
+    if ((int)blockIdx.x >= grp.tile_start[i]) g = i;
+  const dsrg_transpose_problem_t& P = grp.p[g];
+  const int t = blockIdx.x - grp.tile_start[g];
+  const int tc = (P.C + 63) / 64;
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int R = P.R, C = P.C, Rp = P.Rp;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < R && c < C) ? ld_any(P.in, (size_t)r * P.ld_in + c, P.in_dtype) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < C && r < Rp) st_any(P.out, (size_t)c * P.ld_out + r, P.out_dtype, tile[tx][ty + 4 * i]);
+  }
+  if (P.colsum) {                                  // uniform per workgroup
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += tile[ty + 4 * i][tx];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < C) atomicAdd(P.colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+  }
+}
+
 // out[n] += sum over a strip of rows of in[m][n]   (out pre-zeroed; one atomic per column per strip)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int M, int N, int rows_per_block) {
@@ -181,6 +227,29 @@ extern "C" int dsrg_transpose_pad(const void* in, int ld_in, void* out, int ld_o
   else if (out_dtype == DSRG_F32) hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)in, ld_in, (float*)out, ld_out, R, C, Rp, colsum);
   else hipLaunchKernelGGL((transpose_pad_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C, Rp, colsum);
   DSRG_LAUNCH_CHECK("dsrg_transpose_pad");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_transpose_pad_grouped(const dsrg_transpose_problem_t* problems, int nproblems, void* stream) {
+  DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_TRANSPOSES, "dsrg_transpose_pad_grouped: nproblems=%d out of [1,%d]", nproblems, DSRG_MAX_TRANSPOSES);
+  TransposeGroup g;
+  g.n = 0;
+  int tiles = 0;
+  for (int i = 0; i < nproblems; ++i) {
+    const dsrg_transpose_problem_t& p = problems[i];
+    DSRG_CHECK(p.in && p.out && okdt(p.in_dtype) && okdt(p.out_dtype), "dsrg_transpose_pad_grouped: problem %d: bad pointer or dtype", i);
+    DSRG_CHECK(p.R >= 0 && p.C >= 0 && p.Rp >= p.R && p.ld_in >= p.C && p.ld_out >= p.Rp,
+               "dsrg_transpose_pad_grouped: problem %d: bad dims R=%d C=%d Rp=%d ld_in=%d ld_out=%d", i, p.R, p.C, p.Rp, p.ld_in, p.ld_out);
+    if (p.C == 0 || p.Rp == 0) continue;
+    g.p[g.n] = p;
+    g.tile_start[g.n] = tiles;
+    tiles += ((p.C + 63) / 64) * ((p.Rp + 63) / 64);
+    ++g.n;
+  }
+  if (g.n == 0) return DSRG_OK;
+  g.tile_start[g.n] = tiles;
+  hipLaunchKernelGGL(transpose_pad_grouped_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+  DSRG_LAUNCH_CHECK("dsrg_transpose_pad_grouped");
   return DSRG_OK;
 }
 

@@ -149,6 +149,7 @@ def _gemm_grads(items):
     nb = sum(it[1].shape[0] for it in items if it[5])
     dball = torch.zeros(nb, device=items[0][2].device, dtype=torch.float32) if nb else None
     dxp, dwp, dbs, o = [], [], [], 0
+    tr = []                                    # every transpose of this call: one grouped launch
     for x, w, dy, ndx, ndw, ndb in items:
         N, Kd = w.shape
         db = None
@@ -157,12 +158,15 @@ def _gemm_grads(items):
         if ndx:
             Np = (N + 63) // 64 * 64
             dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
-            dxp.append((dyp, K.transpose_pad(w), None, None))            # [M,Np] x [K,Np]^T
+            dxp.append([dyp, len(tr), None, None]); tr.append((w, None))                  # [M,Np] x [K,Np]^T
         if ndw:
-            dwp.append((K.transpose_pad(dy, colsum=db), K.transpose_pad(x), None, None))   # [N,Mp] x [K,Mp]^T
+            dwp.append([len(tr), len(tr) + 1, None, None]); tr += [(dy, db), (x, None)]   # [N,Mp] x [K,Mp]^T
         elif ndb:
             db.copy_(K.colsum(dy))
         dbs.append(db)
+    trs = K.transpose_pad_grouped(tr) if tr else []
+    dxp = [(p[0], trs[p[1]], None, None) for p in dxp]
+    dwp = [(trs[p[0]], trs[p[1]], None, None) for p in dwp]
     dxs = K.gemm(dxp) if dxp else []
     dws = K.gemm(dwp) if dwp else []
     outx, outw = [], []

@@ -363,6 +363,29 @@ def transpose_pad(x, out_dtype=None, pad_to=64, colsum=None):
     return out
 
 
+def transpose_pad_grouped(items, pad_to=64):
+    """items: list of (x [R,C], colsum | None) -> list of [C, Rp] transposes, ONE launch per MAX_TRANSPOSES items."""
+    lib = _lib.load()
+    outs = []
+    for s0 in range(0, len(items), _lib.MAX_TRANSPOSES):
+        chunk = items[s0:s0 + _lib.MAX_TRANSPOSES]
+        arr = (_lib.TransposeProblem * len(chunk))()
+        for i, (x, cs) in enumerate(chunk):
+            _dev(x)
+            R, C_ = x.shape
+            if x.stride(1) != 1:
+                raise _lib.DsrgHipError('transpose_pad_grouped: last dim must be contiguous')
+            Rp = (R + pad_to - 1) // pad_to * pad_to
+            out = torch.empty(C_, Rp, device=x.device, dtype=x.dtype)
+            if cs is not None and (cs.dtype != torch.float32 or cs.numel() != C_ or not cs.is_contiguous()):
+                raise _lib.DsrgHipError('transpose_pad_grouped: colsum must be contiguous fp32 [C]')
+            d = _dt(x)
+            arr[i] = _lib.TransposeProblem(_p(x), _p(out), _p(cs), x.stride(0), Rp, R, C_, Rp, d, d, 0)
+            outs.append(out)
+        _lib.check(lib.dsrg_transpose_pad_grouped(arr, len(chunk), _stream()), 'dsrg_transpose_pad_grouped')
+    return outs
+
+
 def colsum(x):
     """x [M,N] -> fp32 [N]"""
     lib = _lib.load()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 3
+#define DSRG_ABI_VERSION 4
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -243,6 +243,16 @@ int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* wa, const fl
  * bias gradient, taken while dY is being transposed for the weight gradient. */
 int dsrg_transpose_pad(const void* in, int ld_in, void* out, int ld_out, int R, int C, int Rp, int in_dtype,
                        int out_dtype, float* colsum, void* stream);
+
+/* The same for up to DSRG_MAX_TRANSPOSES matrices in ONE launch: the backward of one (grouped) linear layer needs W^T,
+ * dY^T and X^T per problem - autograd of the nn.Linear sites listed at dsrg_gemm_nt (loss.backward(),
+ * PT/train_r2r.py:253, FT/r2r/agent.py:552). */
+#define DSRG_MAX_TRANSPOSES 24
+typedef struct {
+  const void* in; void* out; float* colsum;   /* colsum may be NULL */
+  int32_t ld_in, ld_out, R, C, Rp, in_dtype, out_dtype, pad_;
+} dsrg_transpose_problem_t;
+int dsrg_transpose_pad_grouped(const dsrg_transpose_problem_t* problems, int nproblems, void* stream);
 
 /* out[n] += sum_m in[m, n]  (bias gradient; out is fp32 and must be zeroed by the caller; float atomics). */
 int dsrg_colsum_acc(const void* in, int ld, float* out, int M, int N, int dtype, void* stream);

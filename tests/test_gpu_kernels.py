@@ -273,6 +273,18 @@ def test_transpose_colsum_act(K, dtype):
     cs = torch.zeros(130, device='cuda')           # column sums taken by the transposing kernel itself
     t3 = K.transpose_pad(x, colsum=cs)
     assert torch.equal(t3, t) and (cs - x.float().sum(0)).abs().max().item() <= 1e-3
+    # grouped form: ragged shapes, a strided view, a column-sum rider, one launch
+    a, b, c = _r(1000, 130, dtype=dtype), _r(77, 768, seed=2, dtype=dtype), _r(300, 200, seed=3, dtype=dtype)[:, :70]
+    cs2 = torch.zeros(768, device='cuda')
+    ta, tb, tc = K.transpose_pad_grouped([(a, None), (b, cs2), (c, None)])
+    for src, dst in ((a, ta), (b, tb), (c, tc)):
+        R = src.shape[0]
+        assert dst.shape == (src.shape[1], (R + 63) // 64 * 64) and dst.dtype == dtype
+        assert torch.equal(dst[:, :R], src.t()) and (dst[:, R:] == 0).all()
+    assert (cs2 - b.float().sum(0)).abs().max().item() <= 1e-3
+    many = [(_r(65 + i, 64 + i, seed=10 + i, dtype=dtype), None) for i in range(30)]       # > MAX_TRANSPOSES: two launches
+    for (src, _), dst in zip(many, K.transpose_pad_grouped(many)):
+        assert torch.equal(dst[:, :src.shape[0]], src.t())
     z = _r(64, 3072, dtype=dtype)
     dy = _r(64, 3072, seed=1, dtype=dtype)
     for act in (1, 2, 3):
