@@ -512,6 +512,11 @@ extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, 
     DSRG_CHECK(p.lda % al == 0 && p.ldw % al == 0 && p.lda >= p.K && p.ldw >= p.K,
                "dsrg_gemm_nt: problem %d lda=%d/ldw=%d must be >= K and multiples of %d", i, p.lda, p.ldw, al);
     DSRG_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "dsrg_gemm_nt: problem %d A/W not 16-byte aligned", i);
+    {   // the kernel addresses A and W rows with 32-bit byte offsets from the operand base
+      const size_t esz = dtype == DSRG_BF16 ? 2 : 4;
+      DSRG_CHECK((size_t)p.M * p.lda * esz < ((size_t)1 << 32) && (size_t)p.N * p.ldw * esz < ((size_t)1 << 32),
+                 "dsrg_gemm_nt: problem %d: an operand spans 4 GiB or more (M*lda or N*ldw too large)", i);
+    }
     DSRG_CHECK(p.ldc >= p.N && (!p.residual || p.ldr >= p.N), "dsrg_gemm_nt: problem %d ldc/ldr < N", i);
     DSRG_CHECK(((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.residual & 7) == 0 && ((uintptr_t)p.bias & 15) == 0,
                "dsrg_gemm_nt: problem %d C/residual/bias misaligned", i);

@@ -37,7 +37,9 @@ const char* dsrg_last_error(void);
  * Up to DSRG_MAX_GROUPS independent problems run in one launch (grouped GEMM: the global- and
  * local-branch x-layers, the three RMF poolers, the SAP heads).
  * Requirements: K % 64 == 0 (bf16) / K % 32 == 0 (f32); A, W 16-byte aligned, lda/ldw multiples of
- * 8 (bf16) / 4 (f32).  M, N arbitrary. */
+ * 8 (bf16) / 4 (f32); bias 16-byte aligned; M*lda and N*ldw below 4 GiB in bytes (32-bit row offsets in the kernel).
+ * M, N arbitrary.  With act = GELU and a bf16 output the erf-form GELU is evaluated through a 5-term erfc expansion
+ * (|error| <= 4.3e-7, far below one bf16 ulp); fp32 outputs use libm erff. */
 enum { DSRG_ACT_NONE = 0, DSRG_ACT_GELU = 1, DSRG_ACT_RELU = 2, DSRG_ACT_TANH = 3 };
 #define DSRG_MAX_GROUPS 8
 typedef struct {
