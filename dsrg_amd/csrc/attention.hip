@@ -201,29 +201,38 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
   for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int k0 = 0; k0 < a.Nk; k0 += KC) {
-    __syncthreads();
+  // One chunk of <= 128 keys.  The first chunk is processed outside the loop: inside it the compiler waits for the Q
+  // loads at the loop header, i.e. before the K/V loads are issued (one more exposed memory latency per workgroup).
+  auto chunk = [&](const int k0) {
     const int nk = min(KC, a.Nk - k0);
     const int ntile = ((nk + 31) / 32) * 2;                    // even number of 16-key tiles
-    // ---- stage K (row-major, swizzled) and V (transposed); rows >= nk are zero
+    // ---- stage K (row-major, swizzled) and V (transposed); rows >= nk are zero.  All nine global loads of a thread
+    // are issued UNCONDITIONALLY (row index clamped) before the first LDS write: behind per-row conditions the compiler
+    // waited for each load before issuing the next - nine memory latencies in a row, 9 k of a workgroup's 17 k cycles
+    // (in-kernel stamps, tools/attn_stamps.py).
     {
       const int r = tid >> 3, c = tid & 7;
+      const int key = tid & 127, dc0 = tid >> 7;
+      uint4 kreg[4], vreg[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        kreg[p] = *reinterpret_cast<const uint4*>(Kp + (size_t)(k0 + min(r + 32 * p, nk - 1)) * a.k_rs + c * 8);
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + min(key, nk - 1)) * a.v_rs + (dc0 + 2 * p) * 8);
+      uint8_t mkb = 1;
+      if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + k0 + min(tid & (KC - 1), nk - 1)];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = r + 32 * p;
-        if (row < ntile * 16) {
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (row < nk) v = *reinterpret_cast<const uint4*>(Kp + (size_t)(k0 + row) * a.k_rs + c * 8);
-          *reinterpret_cast<uint4*>(Ks + kswz(row, c)) = v;
-        }
+        if (row < ntile * 16)
+          *reinterpret_cast<uint4*>(Ks + kswz(row, c)) = row < nk ? kreg[p] : make_uint4(0, 0, 0, 0);
       }
-      const int key = tid & 127, dc0 = tid >> 7;
       if (key < ntile * 16) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int dc = dc0 + 2 * p;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (key < nk) v = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + key) * a.v_rs + dc * 8);
+          const uint4 v = key < nk ? vreg[p] : make_uint4(0, 0, 0, 0);
           const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(Vt + (dc * 8 + j) * VRS + key * 2) = e[j];
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
         if (tid < nk) {
           t = 0.f;
           if (a.kmask) {
-            const bool mk = a.kmask[(size_t)b * a.Nk + k0 + tid] != 0;
+            const bool mk = mkb != 0;
             if (a.mask_mode == DSRG_MASK_NEG10000) t = mk ? 0.f : -10000.0f;
             else if (a.mask_mode == DSRG_MASK_NEGINF) t = mk ? 0.f : -INFINITY;
             else if (a.mask_mode == DSRG_MASK_PLUS1) t = mk ? 1.0f : 0.f;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
     }
     __syncthreads();
     ATTN_STAMP(1);
-    if (!active) continue;
+    if (!active) return;
 
     // ---- S^T tiles
     f32x4 s[NKT];
@@ -328,6 +337,11 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
         }
       }
     }
+  };
+  chunk(0);
+  for (int k0 = KC; k0 < a.Nk; k0 += KC) {
+    __syncthreads();                                           // every wave is done with the previous chunk's K / V^T
+    chunk(k0);
   }
   ATTN_STAMP(2);
   if (!active) return;
