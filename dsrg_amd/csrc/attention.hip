@@ -402,35 +402,47 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs
   const T* Op = reinterpret_cast<const T*>(a.O) + b * a.o_bs + h * DH;
   const T* Gp = reinterpret_cast<const T*>(ba.dO) + b * ba.do_bs + h * DH;
   T* dQp = reinterpret_cast<T*>(ba.dQ) + ((size_t)b * a.Nq) * (a.NH * DH) + h * DH;
-  {
-    const int r = tid >> 4, c = (tid & 15) * 4;
-    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
-    if (q0 + r < a.Nq) { qv = ld4(Qp + (size_t)(q0 + r) * a.q_rs + c); gv = ld4(Gp + (size_t)(q0 + r) * ba.do_rs + c); }
-    *reinterpret_cast<float4*>(&Qs[r * DH + c]) = qv;
-    *reinterpret_cast<float4*>(&Gs[r * DH + c]) = gv;
-  }
+  // Global loads are issued unconditionally with clamped row indices and masked afterwards: behind `if (row < N)` the
+  // compiler waits for each load before issuing the next, one exposed memory latency per row group.
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
   float dq[QW], lse[QW], delta[QW], gsw = 0.f, gsb = 0.f;
+  {
+    const int r = tid >> 4, c = (tid & 15) * 4, rq = min(q0 + r, a.Nq - 1);
+    const float4 qv = ld4(Qp + (size_t)rq * a.q_rs + c), gv = ld4(Gp + (size_t)rq * ba.do_rs + c);
+    float gl[QW], ol[QW];
 #pragma unroll
-  for (int i = 0; i < QW; ++i) {
-    const int qg = q0 + wave * QW + i;
-    dq[i] = 0.f; lse[i] = 0.f; delta[i] = 0.f;
-    if (qg < a.Nq) {
-      const float g = Elem<T>::ld(Gp + (size_t)qg * ba.do_rs + lane), o = Elem<T>::ld(Op + (size_t)qg * a.o_rs + lane);
-      delta[i] = wave_sum(g * o);
-      lse[i] = a.lse[((size_t)b * a.NH + h) * a.Nq + qg];
-      if (lane == 0) ba.delta[((size_t)b * a.NH + h) * a.Nq + qg] = delta[i];
+    for (int i = 0; i < QW; ++i) {
+      const int qc = min(q0 + wave * QW + i, a.Nq - 1);
+      gl[i] = Elem<T>::ld(Gp + (size_t)qc * ba.do_rs + lane);
+      ol[i] = Elem<T>::ld(Op + (size_t)qc * a.o_rs + lane);
+      lse[i] = a.lse[((size_t)b * a.NH + h) * a.Nq + qc];
+    }
+    *reinterpret_cast<float4*>(&Qs[r * DH + c]) = q0 + r < a.Nq ? qv : zero4;
+    *reinterpret_cast<float4*>(&Gs[r * DH + c]) = q0 + r < a.Nq ? gv : zero4;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+      const int qg = q0 + wave * QW + i;
+      dq[i] = 0.f;
+      delta[i] = wave_sum(gl[i] * ol[i]);
+      if (qg >= a.Nq) { lse[i] = 0.f; delta[i] = 0.f; }
+      else if (lane == 0) ba.delta[((size_t)b * a.NH + h) * a.Nq + qg] = delta[i];
     }
   }
   for (int k0 = 0; k0 < a.Nk; k0 += KT) {
+    float4 kst[4], vst[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rk = min(k0 + (tid >> 4) + 16 * p, a.Nk - 1), c = (tid & 15) * 4;
+      kst[p] = ld4(Kp + (size_t)rk * a.k_rs + c);
+      vst[p] = ld4(Vp + (size_t)rk * a.v_rs + c);
+    }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
-      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-      if (k0 + r < a.Nk) { kv = ld4(Kp + (size_t)(k0 + r) * a.k_rs + c); vv = ld4(Vp + (size_t)(k0 + r) * a.v_rs + c); }
-      *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = kv;
-      *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = vv;
+      *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = k0 + r < a.Nk ? kst[p] : zero4;
+      *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = k0 + r < a.Nk ? vst[p] : zero4;
     }
     __syncthreads();
     const int key = k0 + lane;
@@ -498,13 +510,22 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
   const T* Kp = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * DH;
   const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
   const T* Gp = reinterpret_cast<const T*>(ba.dO) + b * ba.do_bs + h * DH;
+  // (loads unconditional with clamped rows, masked afterwards: see attention_bwd_dq_kernel)
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    float4 kst[4], vst[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (k0 + r < a.Nk) { kv = ld4(Kp + (size_t)(k0 + r) * a.k_rs + c); vv = ld4(Vp + (size_t)(k0 + r) * a.v_rs + c); }
-    *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = kv;
-    *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = vv;
+    for (int p = 0; p < 4; ++p) {
+      const int rk = min(k0 + (tid >> 4) + 16 * p, a.Nk - 1), c = (tid & 15) * 4;
+      kst[p] = ld4(Kp + (size_t)rk * a.k_rs + c);
+      vst[p] = ld4(Vp + (size_t)rk * a.v_rs + c);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(&Ks[r * KPAD + c]) = k0 + r < a.Nk ? kst[p] : zero4;
+      *reinterpret_cast<float4*>(&Vs[r * KPAD + c]) = k0 + r < a.Nk ? vst[p] : zero4;
+    }
   }
   const int key = k0 + lane;
   bool dead;
@@ -514,17 +535,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 #pragma unroll
   for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
   for (int q0 = 0; q0 < a.Nq; q0 += QPB) {
-    __syncthreads();
     {
-      const int r = tid >> 4, c = (tid & 15) * 4;
-      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
-      if (q0 + r < a.Nq) { qv = ld4(Qp + (size_t)(q0 + r) * a.q_rs + c); gv = ld4(Gp + (size_t)(q0 + r) * ba.do_rs + c); }
-      *reinterpret_cast<float4*>(&Qs[r * DH + c]) = qv;
-      *reinterpret_cast<float4*>(&Gs[r * DH + c]) = gv;
+      const int r = tid >> 4, c = (tid & 15) * 4, rq = min(q0 + r, a.Nq - 1);
+      const float4 qv = ld4(Qp + (size_t)rq * a.q_rs + c), gv = ld4(Gp + (size_t)rq * ba.do_rs + c);
+      const size_t li = ((size_t)b * a.NH + h) * a.Nq + min(q0 + (tid & (QPB - 1)), a.Nq - 1);
+      const float lv = a.lse[li], dl = ba.delta[li];
+      __syncthreads();                               // the previous query block has been consumed
+      *reinterpret_cast<float4*>(&Qs[r * DH + c]) = q0 + r < a.Nq ? qv : zero4;
+      *reinterpret_cast<float4*>(&Gs[r * DH + c]) = q0 + r < a.Nq ? gv : zero4;
       if (tid < QPB) {
         const bool ok = q0 + tid < a.Nq;
-        Ls[tid] = ok ? a.lse[((size_t)b * a.NH + h) * a.Nq + q0 + tid] : 0.f;
-        Dl[tid] = ok ? ba.delta[((size_t)b * a.NH + h) * a.Nq + q0 + tid] : 0.f;
+        Ls[tid] = ok ? lv : 0.f;
+        Dl[tid] = ok ? dl : 0.f;
       }
     }
     __syncthreads();
