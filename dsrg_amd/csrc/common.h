@@ -44,6 +44,11 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// raw (unconverted) 4-element loads: keeping the conversion away from the load lets a batch of loads go out together
+__device__ __forceinline__ float4 raw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 raw_ld4(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+template <typename T> struct Raw4 { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
 __device__ __forceinline__ float4 raw4(float4 v) { return v; }
 __device__ __forceinline__ float4 raw4(uint2 u) {     // 4 packed bf16
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));

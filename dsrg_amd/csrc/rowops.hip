@@ -54,7 +54,10 @@ struct LnArgs {
   float eps;
 };
 
-template <typename TI, typename TO>
+// NV = float4 chunks per lane (ceil(H / 256)), a template parameter so that every load of the row - x, the residual,
+// gamma, beta - is issued up front without a per-lane condition: behind `if (c < H)` the compiler waited for each load
+// before issuing the next (six exposed latencies for a 768-wide row with residual).  Lanes past H load a clamped column.
+template <typename TI, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
   int g = 0;
@@ -64,24 +67,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   const dsrg_ln_problem_t& P = a.p[g];
   const int row = ((int)blockIdx.x - a.blk_start[g]) * WPB + (threadIdx.x >> 6);
   if (row >= P.M) return;
-  const TI* __restrict__ x = reinterpret_cast<const TI*>(P.x);
+  const TI* __restrict__ x = reinterpret_cast<const TI*>(P.x) + (size_t)row * P.ldx;
   const TO* __restrict__ res = reinterpret_cast<const TO*>(P.residual);
   TO* __restrict__ out = reinterpret_cast<TO*>(P.out);
-  const int H = a.H, nv = (H + 255) / 256;
-  float4 v[MAXV];
+  const int H = a.H;
+  float4 v[NV], r[NV], gm[NV], bt[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) {
-      v[i] = ld4(x + (size_t)row * P.ldx + c);
-      if (res) v[i] = f4add(v[i], ld4(res + (size_t)row * P.ldr + c));
-    }
+  for (int i = 0; i < NV; ++i) v[i] = ld4(x + min((i * 64 + lane) * 4, H - 4));
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = ld4(res + (size_t)row * P.ldr + min((i * 64 + lane) * 4, H - 4));
   }
-  ln_row<MAXV>(v, nv, lane, H, P.gamma, P.beta, a.eps);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
+    const int c = min((i * 64 + lane) * 4, H - 4);
+    gm[i] = *reinterpret_cast<const float4*>(P.gamma + c);
+    bt[i] = *reinterpret_cast<const float4*>(P.beta + c);
+  }
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f4add(v[i], r[i]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((i * 64 + lane) * 4 < H) s += v[i].x + v[i].y + v[i].z + v[i].w;
+  const float mean = wave_sum(s) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((i * 64 + lane) * 4 < H) {
+      const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)H + a.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) st4(out + (size_t)row * P.ldo + c, v[i]);
+    if (c < H)
+      st4(out + (size_t)row * P.ldo + c, make_float4((v[i].x - mean) * rstd * gm[i].x + bt[i].x, (v[i].y - mean) * rstd * gm[i].y + bt[i].y,
+                                                     (v[i].z - mean) * rstd * gm[i].z + bt[i].z, (v[i].w - mean) * rstd * gm[i].w + bt[i].w));
   }
 }
 
@@ -117,21 +142,36 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   const int row = blockIdx.x * EWAVES + wave;
   const bool live = row < a.M;
   const T* base = reinterpret_cast<const T*>(a.base);
+  // Loads first, use later: rows past M and columns past H read a clamped (valid) address, and nothing consumes a
+  // loaded value until every load of the row has been issued (a `cond ? load : 0` or an add right behind each load
+  // made the compiler wait for it before issuing the next: ~12 memory latencies in a row in the first version's ISA).
+  const int rowc = min(row, a.M - 1);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float f[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) f[k] = (live && a.feat && k < a.F) ? a.feat[(size_t)row * a.ldf + k] : 0.f;
-  const int i1 = (live && a.E1) ? embed_index(a.i1, row) : 0, i2 = (live && a.E2) ? embed_index(a.i2, row) : 0;
+  for (int k = 0; k < 16; ++k) f[k] = 0.f;
+  if (a.feat) {                                     // uniform
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < a.F) f[k] = a.feat[(size_t)rowc * a.ldf + k];
+  }
+  const int i1 = a.E1 ? embed_index(a.i1, rowc) : 0, i2 = a.E2 ? embed_index(a.i2, rowc) : 0;
+  float4 lb[MAXV], l1[MAXV], l2[MAXV], lv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) {                                   // uniform
+      const int cc = min((i * 64 + lane) * 4, H - 4);
+      lb[i] = base ? ld4(base + (size_t)rowc * a.ldb + cc) : z4;
+      l1[i] = a.E1 ? *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + cc) : z4;
+      l2[i] = a.E2 ? *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + cc) : z4;
+      lv[i] = a.vec ? *reinterpret_cast<const float4*>(a.vec + cc) : z4;
+    }
+  }
   float4 add[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    add[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live && i < nv && c < H) {
-      if (base) add[i] = ld4(base + (size_t)row * a.ldb + c);
-      if (a.E1) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c));
-      if (a.E2) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c));
-      if (a.vec) add[i] = f4add(add[i], *reinterpret_cast<const float4*>(a.vec + c));
-    }
+    add[i] = z4;
+    if (live && i < nv && (i * 64 + lane) * 4 < H) add[i] = f4add(f4add(lb[i], l1[i]), f4add(l2[i], lv[i]));
   }
   if (a.feat) {
     for (int j = threadIdx.x; j < H * a.F; j += 64 * EWAVES) {
@@ -196,21 +236,27 @@ __global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x,
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (H + 255) / 256;
   const T* xb = x + (size_t)b * V * H;
-  float4 row[GVPW][MAXV];
+  // every load of the wave goes out first, unconditionally (view / column clamped), and is masked afterwards: a
+  // `cond ? load : 0` consumes each load at once and the compiler then waits for it before issuing the next
+  // (16 memory latencies in a row in the ISA of the first version)
+  float4 row[GVPW][MAXV], ww[MAXV];
+  typename Raw4<T>::type raw[GVPW][MAXV];          // unconverted: the bf16 -> f32 shifts would consume each load at once
 #pragma unroll
   for (int r = 0; r < GVPW; ++r)
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int v = wave + GWAVES * r, c = (i * 64 + lane) * 4;
-      row[r][i] = (v < V && i < nv && c < H) ? ld4(xb + (size_t)v * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  float4 ww[MAXV];
+    for (int i = 0; i < MAXV; ++i)
+      raw[r][i] = raw_ld4(xb + (size_t)min(wave + GWAVES * r, V - 1) * H + min((i * 64 + lane) * 4, H - 4));
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) ww[i] = *reinterpret_cast<const float4*>(w + min((i * 64 + lane) * 4, H - 4));
+  const float b0 = bias[0];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    ww[i] = (i < nv && c < H) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okc = i < nv && (i * 64 + lane) * 4 < H;
+    if (!okc) ww[i] = z4;
+#pragma unroll
+    for (int r = 0; r < GVPW; ++r) row[r][i] = (okc && wave + GWAVES * r < V) ? raw4(raw[r][i]) : z4;
   }
-  const float b0 = bias[0];
 #pragma unroll
   for (int r = 0; r < GVPW; ++r) {
     const int v = wave + GWAVES * r;
@@ -448,9 +494,19 @@ extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int
   a.blk_start[a.nprob] = blocks;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(blocks), block(256);
-  if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, a);
-  else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
+#define DSRG_LN_LAUNCH(NV_)                                                                                              \
+  do {                                                                                                                  \
+    if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float, NV_>), grid, block, 0, s, a);         \
+    else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t, NV_>), grid, block, 0, s, a);    \
+    else hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t, NV_>), grid, block, 0, s, a);                             \
+  } while (0)
+  switch ((a.H + 255) / 256) {
+    case 1: DSRG_LN_LAUNCH(1); break;
+    case 2: DSRG_LN_LAUNCH(2); break;
+    case 3: DSRG_LN_LAUNCH(3); break;
+    default: DSRG_LN_LAUNCH(4); break;
+  }
+#undef DSRG_LN_LAUNCH
   DSRG_LAUNCH_CHECK("dsrg_layernorm_fwd");
   return DSRG_OK;
 }
