@@ -5,6 +5,7 @@
 //   grid = (ceil(Nq/16), NH, B), 256 threads = 4 waves, each wave owns 4 query rows.
 //   scores : lane <-> key   (K tile rows padded to 68 floats: conflict-free ds_read_b128)
 //   P·V    : lane <-> d     (V tile row-major: conflict-free ds_read_b32, P broadcast from LDS)
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -168,10 +169,10 @@ __device__ unsigned long long g_attn_stamps[16384 * 4];
 #define ATTN_STAMP(i) do {} while (0)
 #endif
 #ifndef ATTN_MFMA_MIN_WAVES
-#define ATTN_MFMA_MIN_WAVES 1
+#define ATTN_MFMA_MIN_WAVES 3
 #endif
 template <bool DROP>
-__global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
+__global__ __launch_bounds__(256, DROP ? 2 : ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
   ATTN_STAMP(0);
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
@@ -256,12 +257,16 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
     ATTN_STAMP(1);
     if (!active) return;
 
+    // The score / softmax / P.V part is specialised on the number of 16-key tiles (2, 4, 6, 8): with a run-time tile
+    // count every tile sat in its own basic block and its LDS reads could not be scheduled ahead of the previous tile's MFMAs.
+    auto compute = [&](auto nt_tag) {
+    constexpr int NTL = decltype(nt_tag)::value;
     // ---- S^T tiles
-    f32x4 s[NKT];
+    f32x4 s[NTL];
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
+    for (int t = 0; t < NTL; ++t) {
       s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < ntile) {
+      {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kswz(t * 16 + c16, g + 4 * kk));
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
     // ---- scale + mask + sprel, running max
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      if (t < ntile) {
+    for (int t = 0; t < NTL; ++t) {
+      {
         const float4 mk = *reinterpret_cast<const float4*>(&mt[t * 16 + 4 * g]);
         const float mm[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t)
-      if (t < ntile) {
+    for (int t = 0; t < NTL; ++t)
+      {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __expf(s[t][r] - m_safe);
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
       const float ik = 1.0f / (1.0f - a.p_drop);
       const size_t rbase = (((size_t)b * a.NH + h) * a.Nq + qrow) * a.Nk + k0;
 #pragma unroll
-      for (int t = 0; t < NKT; ++t)
-        if (t < ntile) {
+      for (int t = 0; t < NTL; ++t)
+        {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kl = t * 16 + 4 * g + r;
@@ -323,8 +328,8 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
     for (int i = 0; i < 4; ++i) o[i] *= alpha;
     // ---- O^T += V^T · P^T
 #pragma unroll
-    for (int j = 0; j < NKT / 2; ++j) {
-      if (2 * j < ntile) {
+    for (int j = 0; j < NTL / 2; ++j) {
+      {
         bf16x8 pf;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
@@ -336,6 +341,13 @@ __global__ __launch_bounds__(256, ATTN_MFMA_MIN_WAVES) void attention_mfma_kerne
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
         }
       }
+    }
+    };
+    switch (ntile) {
+      case 2: compute(std::integral_constant<int, 2>{}); break;
+      case 4: compute(std::integral_constant<int, 4>{}); break;
+      case 6: compute(std::integral_constant<int, 6>{}); break;
+      default: compute(std::integral_constant<int, 8>{}); break;
     }
   };
   chunk(0);
