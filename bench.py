@@ -163,14 +163,15 @@ def gemm_roofline(step_fn, dtype):
     d = by_tile[dom]
     peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
-    sig = 'gemm_nt_kernel<%s, %s, %d, %d, 2>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
-                                                  'float' if dom[2] == 0 else 'unsigned short', dom[0], dom[1])
+    # (every ring depth of the tile variant: the trace key is the tile, the ring depth is the library's choice per launch)
+    sig = 'gemm_nt_kernel<%s, %s, %d, %d, ' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
+                                               'float' if dom[2] == 0 else 'unsigned short', dom[0], dom[1])
     traffic, src = pmc_traffic(sig, d['grids'])
     return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
             'frac': d['flops'] / d['time'] / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
             'traffic_source': src, 'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
             'algorithmic_flops_per_launch': d['flops'] / d['launches'],
-            'kernel': 'gemm_nt_kernel<%s,%s,%d,%d,2>' % ('bf16' if dtype == torch.bfloat16 else 'f32', 'f32' if dom[2] == 0 else 'bf16', dom[0], dom[1]),
+            'kernel': 'gemm_nt_kernel<%s,%s,%d,%d,*>' % ('bf16' if dtype == torch.bfloat16 else 'f32', 'f32' if dom[2] == 0 else 'bf16', dom[0], dom[1]),
             'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
             'all_gemm_us_per_step': tot_t * 1e6}
