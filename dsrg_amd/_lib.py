@@ -11,7 +11,12 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
+
+
+class HeadTailProblem(C.Structure):
+    _fields_ = [('h', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p),
+                ('score', C.c_void_p), ('M', C.c_int32), ('ldh', C.c_int32)]
 
 
 class TransposeProblem(C.Structure):
@@ -83,6 +88,7 @@ SIGNATURES = {
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_transpose_pad': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'dsrg_head_tail_fwd_grouped': (C.c_int, [C.POINTER(HeadTailProblem), _I, _I, C.c_float, _P]),
     'dsrg_transpose_pad_grouped': (C.c_int, [C.POINTER(TransposeProblem), _I, _P]),
     'dsrg_colsum_acc': (C.c_int, [_P, _I, _P, _I, _I, _I, _P]),
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),

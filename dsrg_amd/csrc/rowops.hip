@@ -326,6 +326,38 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
   if (lane == 0) score[row] = s + b2[0];
 }
 
+struct HeadTailGroup {
+  dsrg_head_tail_problem_t p[DSRG_MAX_GROUPS];
+  int blk_start[DSRG_MAX_GROUPS + 1];
+  int n, H;
+  float eps;
+};
+__global__ __launch_bounds__(256) void head_tail_grouped_kernel(const HeadTailGroup a) {
+  const int lane = threadIdx.x & 63;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.blk_start[i]) g = i;
+  const dsrg_head_tail_problem_t& P = a.p[g];
+  const int row = ((int)blockIdx.x - a.blk_start[g]) * WPB + (threadIdx.x >> 6);
+  if (row >= P.M) return;
+  const int H = a.H, nv = (H + 255) / 256;
+  float4 v[MAXV], ww[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = min((i * 64 + lane) * 4, H - 4);
+    v[i] = *reinterpret_cast<const float4*>(P.h + (size_t)row * P.ldh + c);
+    ww[i] = *reinterpret_cast<const float4*>(P.w2 + c);
+  }
+  ln_row<MAXV>(v, nv, lane, H, P.gamma, P.beta, a.eps);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (i < nv && (i * 64 + lane) * 4 < H) s += v[i].x * ww[i].x + v[i].y * ww[i].y + v[i].z * ww[i].z + v[i].w * ww[i].w;
+  s = wave_sum(s);
+  if (lane == 0) P.score[row] = s + P.b2[0];
+}
+
 // one wave per episode; local logits are staged in LDS for the gather by graph node
 constexpr int NAV_MAX_VP = 1024;
 __global__ __launch_bounds__(64) void nav_logits_kernel(const float* __restrict__ g_raw, const float* __restrict__ l_raw,
@@ -592,6 +624,31 @@ extern "C" int dsrg_head_tail_fwd(const float* h, int ldh, const float* gamma, c
   if (M <= 0) return DSRG_OK;
   hipLaunchKernelGGL(head_tail_kernel, dim3((M + WPB - 1) / WPB), dim3(256), 0, (hipStream_t)stream, h, ldh, gamma, beta, w2, b2, eps, score, M, H);
   DSRG_LAUNCH_CHECK("dsrg_head_tail_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_head_tail_fwd_grouped(const dsrg_head_tail_problem_t* problems, int nproblems, int H, float eps, void* stream) {
+  DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS, "dsrg_head_tail_fwd_grouped: nproblems=%d out of [1,%d]", nproblems, DSRG_MAX_GROUPS);
+  DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_head_tail_fwd_grouped: bad H=%d", H);
+  HeadTailGroup g;
+  g.n = 0; g.H = H; g.eps = eps;
+  int blocks = 0;
+  for (int i = 0; i < nproblems; ++i) {
+    const dsrg_head_tail_problem_t& p = problems[i];
+    DSRG_CHECK(p.M >= 0, "dsrg_head_tail_fwd_grouped: problem %d has M < 0", i);
+    if (p.M == 0) continue;
+    DSRG_CHECK(p.h && p.gamma && p.beta && p.w2 && p.b2 && p.score, "dsrg_head_tail_fwd_grouped: problem %d has a null pointer", i);
+    DSRG_CHECK(p.ldh % 4 == 0 && p.ldh >= H && al16(p.h) && al16(p.gamma) && al16(p.beta) && al16(p.w2),
+               "dsrg_head_tail_fwd_grouped: problem %d: bad ldh or misaligned pointer", i);
+    g.p[g.n] = p;
+    g.blk_start[g.n] = blocks;
+    blocks += (p.M + WPB - 1) / WPB;
+    ++g.n;
+  }
+  if (g.n == 0) return DSRG_OK;
+  g.blk_start[g.n] = blocks;
+  hipLaunchKernelGGL(head_tail_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  DSRG_LAUNCH_CHECK("dsrg_head_tail_fwd_grouped");
   return DSRG_OK;
 }
 

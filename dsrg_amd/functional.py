@@ -511,6 +511,14 @@ def head_tail(h, gamma, beta, w2, b2, eps=1e-12):
     return K.head_tail(h, gamma, beta, w2, b2, eps)
 
 
+def head_tail_grouped(items, eps=1e-12):
+    """items: list of (h, gamma, beta, w2, b2): all ClsPrediction tails of a step in ONE launch (no-grad); with autograd on
+    each head keeps its own node."""
+    if any(_needs_grad(it) for it in items):
+        return [head_tail(*it, eps) for it in items]
+    return K.head_tail_grouped(items, eps)
+
+
 class _NavLogitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, l, f, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):

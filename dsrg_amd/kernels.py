@@ -320,6 +320,25 @@ def head_tail(h, gamma, beta, w2, b2, eps=1e-12):
     return score
 
 
+def head_tail_grouped(items, eps=1e-12):
+    """items: list (<= MAX_GROUPS) of (h fp32 [..,H], gamma, beta, w2, b2) sharing H -> list of scores [..], ONE launch"""
+    lib = _lib.load()
+    n = len(items)
+    arr = (_lib.HeadTailProblem * n)()
+    outs = []
+    H = items[0][0].shape[-1]
+    for i, (h, gamma, beta, w2, b2) in enumerate(items):
+        _dev(h)
+        if h.dtype != torch.float32 or h.shape[-1] != H:
+            raise _lib.DsrgHipError('head_tail_grouped: h must be fp32 with a common width')
+        M, ldh = _rows(h)
+        score = torch.empty(h.shape[:-1], device=h.device, dtype=torch.float32)
+        arr[i] = _lib.HeadTailProblem(_p(h), _p(gamma), _p(beta), _p(w2), _p(b2), _p(score), M, ldh)
+        outs.append(score)
+    _lib.check(lib.dsrg_head_tail_fwd_grouped(arr, n, H, float(eps), _stream()), 'dsrg_head_tail_fwd_grouped')
+    return outs
+
+
 def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
     lib = _lib.load()
     _dev(g_raw)

@@ -603,7 +603,7 @@ class GlocalTextPathNavCMT(nn.Module):
     def _heads(self, W, items):
         """items: list of (key, x [..,K]) -> raw scores; first layers grouped in one launch (vilmodel.py:616-628)."""
         h = Fn.linear_grouped([(x, W[k + '.l1.w'], W[k + '.l1.b'], None) for k, x in items], act=ACT_RELU, out_f32=True)
-        return [Fn.head_tail(h[j], W[k + '.ln.g'], W[k + '.ln.b'], W[k + '.w2'], W[k + '.b2']) for j, (k, _) in enumerate(items)]
+        return Fn.head_tail_grouped([(h[j], W[k + '.ln.g'], W[k + '.ln.b'], W[k + '.w2'], W[k + '.b2']) for j, (k, _) in enumerate(items)])
 
     def _rmf(self, W, g, v, txt):
         """RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN"""

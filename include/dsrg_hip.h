@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 4
+#define DSRG_ABI_VERSION 5
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -156,6 +156,14 @@ int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* ou
  * (net.2 LayerNorm eps 1e-12, net.3 Linear(H,1)).  h fp32 [M,H] (ldh); score fp32 [M]. */
 int dsrg_head_tail_fwd(const float* h, int ldh, const float* gamma, const float* beta, const float* w2,
                        const float* b2, float eps, float* score, int M, int H, void* stream);
+
+/* The same for up to DSRG_MAX_GROUPS heads in ONE launch (global, local, fuse and object heads of a navigation step,
+ * vilmodel.py:773-785): per problem its own rows, LayerNorm affine, projection and output. */
+typedef struct {
+  const float* h; const float* gamma; const float* beta; const float* w2; const float* b2; float* score;
+  int32_t M, ldh;
+} dsrg_head_tail_problem_t;
+int dsrg_head_tail_fwd_grouped(const dsrg_head_tail_problem_t* problems, int nproblems, int H, float eps, void* stream);
 
 /* ---- navigation logits: dynamic fusion + masking + global/local logit fusion ------------------------
  * fw = sigmoid(fuse_raw[b]);  gl = g_raw*fw, ll = l_raw*(1-fw);  -inf masking

@@ -219,6 +219,13 @@ def test_pool_mean_head_blend(K, dtype):
     sc = K.head_tail(h, g, be, w2, b2)
     ref = torch.nn.functional.layer_norm(h, (H,), g, be, 1e-12) @ w2 + b2
     assert (sc - ref).abs().max().item() <= 2e-5
+    # all heads of a step in one launch: different row counts, a 3-D input, per-head parameters
+    h2, h3 = _r(7, 5, H, seed=11).relu(), _r(3, H, seed=12).relu()
+    g2, be2, w22, b22 = 1 + 0.1 * _r(H, seed=13), 0.1 * _r(H, seed=14), _r(H, seed=15, scale=0.05), _r(1, seed=16)
+    s1, s2, s3 = K.head_tail_grouped([(h, g, be, w2, b2), (h2, g2, be2, w22, b22), (h3, g, be, w22, b2)])
+    assert s1.shape == sc.shape and s2.shape == (7, 5) and s3.shape == (3,)
+    assert (s1 - sc).abs().max().item() <= 2e-6
+    assert (s2 - K.head_tail(h2, g2, be2, w22, b22)).abs().max().item() <= 2e-6 and (s3 - K.head_tail(h3, g, be, w22, b2)).abs().max().item() <= 2e-6
     aug, xx = _r(50, H, dtype=dtype), _r(50, H, seed=1, dtype=dtype)
     wa, ba, wo, bo = _r(H, scale=0.05, seed=7), _r(1, seed=8), _r(H, scale=0.05, seed=9), _r(1, seed=10)
     out = K.igl_blend(aug, xx, wa, ba, wo, bo)
