@@ -19,6 +19,9 @@ SHAPES = [  # name, [(M,N,K)...] grouped, act, out_f32, residual
     ('l.qkv M=2432 N=2304 K=768', [(2432, 2304, 768)], 0, False, False),
     ('l.ff1 M=2432 N=3072 K=768 gelu', [(2432, 3072, 768)], 1, False, False),
     ('l.ff2 M=2432 N=768 K=3072 f32out+res', [(2432, 768, 3072)], 0, True, True),
+    ('g.ff2 split-K 2', [(1280, 768, 1536)] * 2, 0, True, True),
+    ('g.ff2 split-K 3', [(1280, 768, 1024)] * 3, 0, True, True),
+    ('l.ff2 split-K 2', [(2432, 768, 1536)] * 2, 0, True, True),
     ('x.ff2 split-K 2 (4 problems K=1536)', [(1280, 768, 1536), (2432, 768, 1536)] * 2, 0, True, True),
     ('x.ff2 split-K 3 (6 problems K=1024)', [(1280, 768, 1024), (2432, 768, 1024)] * 3, 0, True, True),
     ('x.cq split-K 2 (4 problems K=384)', [(1280, 768, 384), (2432, 768, 384)] * 2, 0, True, True),
