@@ -371,9 +371,13 @@ def main():
             torch.cuda.synchronize()
         out['language_mode'] = {'ms_per_call': (time.perf_counter() - t1) / 5 * 1e3, 'episodes_per_call': B, 'launch': 'eager'}
         if not a.no_roofline:
-            def one_step():
-                with torch.no_grad():
-                    runner._body()
+            def one_step():                      # the launches of the schedule the graph replays (two-stream branches)
+                model.split_when_eager = not a.eager
+                try:
+                    with torch.no_grad():
+                        runner._body()
+                finally:
+                    model.split_when_eager = False
             out['roofline'] = gemm_roofline(one_step, dtype)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, sd, lbs[0], pb, nb, dims)

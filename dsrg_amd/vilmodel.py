@@ -174,6 +174,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self._wcache, self._kv_cache, self._wplan, self._wgrad, self._wtoken = None, None, None, None, object()
         self._side_stream, self.overlap_streams, self._fork_depth = None, True, 0
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams (3.6 % faster than grouped launches at R2R shapes; 0 = grouped)
+        self.split_when_eager = False          # bench.py sets it to trace the captured schedule's launches eagerly
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
     # ---------------------------------------------------------------- construction helpers
@@ -646,8 +647,10 @@ class GlocalTextPathNavCMT(nn.Module):
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
         # two streams pay when the branches are of similar size (R2R: 20 vs 38 tokens); with one much longer branch
         # (REVERIE: 20 vs 58) the grouped launches are faster (measured, bench.py --config c3)
+        # (under HIP-graph capture only: launched eagerly from Python the step is host-bound and the 40 % more launches
+        # of the split schedule cost 3 %)
         if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
-                and max(G, Vp) <= 2.7 * min(G, Vp)):
+                and max(G, Vp) <= 2.7 * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
             lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
             g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
             v = lj()
