@@ -57,20 +57,26 @@ def _same(a, b, tol):
     return float((a[fa].float() - b[fb].float()).abs().max()) <= tol
 
 
-@pytest.mark.parametrize('L,G,B', [(80, 20, 64), (250, 100, 32)])
-def test_full_size_chain_matches_oracle(L, G, B):
-    """configs[1] at full batch and the configs[4] shapes: 3-step recurrent chain, HIP fp32 vs the CPU oracle."""
+@pytest.mark.parametrize('L,G,B,reverie', [(80, 20, 64, False), (250, 100, 32, False), (80, 20, 64, True)])
+def test_full_size_chain_matches_oracle(L, G, B, reverie):
+    """configs[1] and configs[2] (REVERIE, 20 object tokens, OG head) at full batch and the configs[4] shapes: recurrent
+    chain, HIP fp32 vs the CPU oracle."""
     from dsrg_amd.config import DSRGConfig
     from oracle import dsrg_oracle
-    sd = common.synth_sd('r2r_c1')
-    m = _model(torch.float32, sd)
-    meta = [B, L, G, 3, 42, 0, 0]
+    tag = 'reverie_c3' if reverie else 'r2r_c1'
+    sd = common.synth_sd(tag)
+    if reverie:
+        from dsrg_amd.vilmodel_reverie import GlocalTextPathNavCMT
+        m = GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict=sd, compute_dtype=torch.float32).cuda().eval()
+    else:
+        m = _model(torch.float32, sd)
+    meta = [B, L, G, 3, 42, int(reverie), 20 if reverie else 0]
     steps = 3 if L == 80 else 2
     with torch.no_grad():
         out = common.run_chain(lambda mode, b: m(mode, b), meta, device='cuda', steps=steps)
-        ref = common.run_chain(lambda mode, b: dsrg_oracle.forward(sd, DSRGConfig(), mode, b), meta, device='cpu', steps=steps)
+        ref = common.run_chain(lambda mode, b: dsrg_oracle.forward(sd, DSRGConfig(), mode, b, reverie=reverie), meta, device='cpu', steps=steps)
     errs = common.compare(out, ref, tol=1e-3, logit_tol=1e-3, steps=steps)
-    print('B=%d L=%d G=%d fp32 vs oracle' % (B, L, G), {k: '%.1e' % v for k, v in errs.items() if 'logits' in k})
+    print('B=%d L=%d G=%d reverie=%s fp32 vs oracle' % (B, L, G, reverie), {k: '%.1e' % v for k, v in errs.items() if 'logits' in k})
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
