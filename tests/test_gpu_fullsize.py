@@ -161,3 +161,25 @@ def test_bf16_agrees_with_fp32_on_clear_margins_at_full_batch():
     assert clear.sum() >= 32
     a16, a32 = o16['fused_logits'].float().argmax(1).cpu().numpy(), f.argmax(1)
     assert (a16[clear] == a32[clear]).all()
+
+
+@pytest.mark.parametrize('task', ['mlm', 'mrc', 'sap'])
+def test_full_size_pretraining_losses_match_oracle(task):
+    """Pre-training twin at the bench's C4 shapes (24 trajectories of 4-7 steps, 80 instruction tokens): the per-sample
+    loss vector of the fp32 HIP path against the CPU oracle on the same batch, within 1e-3 (dropout 0, forward only;
+    the golden-vector tests in test_gpu_pretrain.py hold the gradients)."""
+    from dsrg_amd.config import DSRGConfig
+    from oracle import pretrain_oracle
+    from tests.test_gpu_pretrain import _model as pt_model
+    from tests.test_oracle_pt_golden import PT_CFG
+    torch.set_num_threads(8)
+    raw = synth.pretrain_batch(24, 80, 3, 77, task, min_steps=4, max_steps=7)
+    m = pt_model(torch.float32)
+    with torch.no_grad():
+        mine = m(common.to_t(raw, 'cuda'), task, compute_loss=True).float().cpu().numpy()
+    sd = common.synth_sd('r2r_pt')
+    sd['bert.embeddings.word_embeddings.weight'] = sd['mlm_head.predictions.decoder.weight']   # tied, see the golden test
+    with torch.no_grad():
+        want = pretrain_oracle.forward(sd, DSRGConfig(**PT_CFG), common.to_t(raw), task, True).numpy()
+    assert mine.shape == want.shape and np.isfinite(mine).all()
+    assert np.abs(mine - want).max() <= 1e-3, (task, np.abs(mine - want).max())
