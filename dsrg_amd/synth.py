@@ -156,7 +156,7 @@ def navigation_batch(B, G=20, Vp=38, seed=0, ncand=None, nav_types=None, vp_lens
     visited = np.zeros((B, G), bool)
     step_ids = np.zeros((B, G), np.int64)
     for i in range(B):
-        nv, gl, nc = int(nvis[i]), int(glen[i]), int(ncand[i])
+        nv, gl, nc = min(int(nvis[i]), max(int(glen[i]) - 2, 0)), int(glen[i]), int(ncand[i])
         names = [None, None] + ['vp%d_%d' % (i, k) for k in range(gl - 2)]
         gmap_vpids.append(names)
         visited[i, 2:2 + nv] = True
@@ -165,8 +165,8 @@ def navigation_batch(B, G=20, Vp=38, seed=0, ncand=None, nav_types=None, vp_lens
         # candidates: (maybe) the previously visited node + unvisited nodes, in a hashed order
         order = np.argsort(uniform('cand_order%d' % i, (len(unv),), seed))
         cands = [unv[j] for j in order[:nc]]
-        if nv > 1 and nc > 1:
-            cands[int(integers('bwpos%d' % i, (), 0, nc, seed))] = names[2 + nv - 2]
+        if nv > 1 and nc > 1 and cands:             # small graphs: fewer unvisited nodes than candidates
+            cands[int(integers('bwpos%d' % i, (), 0, nc, seed)) % len(cands)] = names[2 + nv - 2]
         cand_vpids.append([None, None] + cands)
     gm = np.arange(G)[None] < glen[:, None]
     gmap_masks = gm.copy(); gmap_masks[:, 1] = False

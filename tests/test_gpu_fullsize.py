@@ -183,3 +183,24 @@ def test_full_size_pretraining_losses_match_oracle(task):
         want = pretrain_oracle.forward(sd, DSRGConfig(**PT_CFG), common.to_t(raw), task, True).numpy()
     assert mine.shape == want.shape and np.isfinite(mine).all()
     assert np.abs(mine - want).max() <= 1e-3, (task, np.abs(mine - want).max())
+
+
+@pytest.mark.parametrize('reverie', [False, True])
+@pytest.mark.parametrize('B,L,G', [(1, 5, 3), (3, 33, 7), (65, 17, 13)])
+def test_minimal_and_ragged_shapes_match_oracle(B, L, G, reverie):
+    """The other end of the size range: one episode whose graph map is [stop, MEM, current node] and whose
+    instruction is 5 tokens; odd sizes that leave a partial tile in every GEMM, attention and row kernel (B=65 is one
+    row past a 64-row tile). Two recurrent steps, HIP fp32 vs the CPU oracle, same gates as the full-size chain."""
+    from dsrg_amd.config import DSRGConfig
+    from oracle import dsrg_oracle
+    sd = common.synth_sd('reverie_c3' if reverie else 'r2r_c1')
+    if reverie:
+        from dsrg_amd.vilmodel_reverie import GlocalTextPathNavCMT
+        m = GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict=sd, compute_dtype=torch.float32).cuda().eval()
+    else:
+        m = _model(torch.float32, sd)
+    meta = [B, L, G, 3, 11, int(reverie), 20 if reverie else 0]
+    with torch.no_grad():
+        out = common.run_chain(lambda mode, b: m(mode, b), meta, device='cuda', steps=2)
+        ref = common.run_chain(lambda mode, b: dsrg_oracle.forward(sd, DSRGConfig(), mode, b, reverie=reverie), meta, device='cpu', steps=2)
+    common.compare(out, ref, tol=1e-3, logit_tol=1e-3, steps=2)
