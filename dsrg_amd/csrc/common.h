@@ -112,3 +112,24 @@ void dsrg_set_error(const char* fmt, ...);
       return DSRG_ELAUNCH;                                                   \
     }                                                                        \
   } while (0)
+
+// Stage the feature projection Wf [H,F] transposed into LDS (WT[k*HS + h]) with NT threads.  Eight loads are issued
+// before the first LDS store: a plain `WT[..] = Wf[j]` loop with a run-time trip count compiles to load / wait / store
+// per iteration, i.e. one memory latency per 4 bytes per thread (21 in a row for H*F = 5376 and 256 threads).
+template <int NT>
+__device__ __forceinline__ void stage_wt(float* WT, const float* __restrict__ Wf, int H, int F, int HS, int tid) {
+  const int n = H * F;
+  for (int j0 = tid; j0 < n; j0 += NT * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = Wf[min(j0 + u * NT, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * NT;
+      if (j < n) {
+        const int h = j / F, k = j - h * F;
+        WT[k * HS + h] = v[u];
+      }
+    }
+  }
+}

@@ -147,14 +147,8 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   // made the compiler wait for it before issuing the next: ~12 memory latencies in a row in the first version's ISA).
   const int rowc = min(row, a.M - 1);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float f[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) f[k] = 0.f;
-  if (a.feat) {                                     // uniform
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (k < a.F) f[k] = a.feat[(size_t)rowc * a.ldf + k];
-  }
+  // the row's features: ONE load (lane k holds feature k), broadcast below - F conditional loads were F latencies in a row
+  const float fl = a.feat ? a.feat[(size_t)rowc * a.ldf + min(lane, a.F - 1)] : 0.f;
   const int i1 = a.E1 ? embed_index(a.i1, rowc) : 0, i2 = a.E2 ? embed_index(a.i2, rowc) : 0;
   float4 lb[MAXV], l1[MAXV], l2[MAXV], lv[MAXV];
 #pragma unroll
@@ -174,10 +168,7 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
     if (live && i < nv && (i * 64 + lane) * 4 < H) add[i] = f4add(f4add(lb[i], l1[i]), f4add(l2[i], lv[i]));
   }
   if (a.feat) {
-    for (int j = threadIdx.x; j < H * a.F; j += 64 * EWAVES) {
-      const int h = j / a.F, k = j - h * a.F;
-      WT[k * HS + h] = a.Wf[j];
-    }
+    stage_wt<64 * EWAVES>(WT, a.Wf, H, a.F, HS, threadIdx.x);
     __syncthreads();
   }
   if (!live) return;
@@ -185,6 +176,9 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.feat) {
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = k < a.F ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fl), k)) : 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;

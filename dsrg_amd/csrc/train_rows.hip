@@ -282,9 +282,14 @@ __global__ __launch_bounds__(256) void igl_blend_bwd_kernel(const T* __restrict_
 
 // ---- token-embedding sums backward (forward: embed_ln_kernel, rowops.hip)
 //   out = LNo( base + LNf(Wf.feat + bf) + E1[i1] + E2[i2] + vec )     (every term optional)
-// One wave per row, a strip of rows per workgroup.  Column-vector gradients and dWf are summed in LDS (ds_add_f32) and
-// leave with one global atomic per element per workgroup; table rows get their dz by global atomics (dense fp32 tables).
+// One wave per row, a strip of rows per workgroup.  A lane owns the same 4*NV columns in every row, so every column-vector
+// gradient, dWf (FR = F rounded up to 8 / 16 columns) and the gradient of a table with a handful of rows (nav / token
+// types: TS of them) are summed over the wave's rows in REGISTERS.  At the end the four waves' sums meet in a [4][H] LDS
+// slab, one vector at a time, with plain stores (no LDS atomics: a wave-wide ds_add_f32 costs ~1000 cycles here - the
+// first version spent ~15 of them per element per ROW and took 110-750 us per launch), and leave with one global float
+// atomic per element per workgroup.  Rows of large tables get their dz by global atomics (dense fp32 tables).
 constexpr int EMB_SMALL = 4;
+#define ROWN(i, c) for (int i = 0; i < NV; ++i) { const int c = (i * 64 + lane) * 4; if (c < H)
 __device__ __forceinline__ int embed_index_b(const void* p, int kind, int stride, int div, int row) {
   const size_t o = (size_t)(row / div) * stride;
   if (kind == DSRG_IDX_I32) return reinterpret_cast<const int32_t*>(p)[o];
@@ -292,120 +297,178 @@ __device__ __forceinline__ int embed_index_b(const void* p, int kind, int stride
   return (int)reinterpret_cast<const float*>(p)[o];
 }
 
-template <typename T>
+template <typename T, int NV, int FR, int TS>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_args_t a, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int H = a.H, F = a.F, nv = (H + 255) / 256, HS = H + 4;
-  float* WT = lds;                                   // [F][HS] forward weight, transposed
-  float* dWT = WT + (a.feat ? F * HS : 0);           // [F][HS] its gradient
-  float* col = dWT + (a.feat ? F * HS : 0);          // [6][H]: dbf, dlnf_g, dlnf_b, dvec, dlno_g, dlno_b
-  // tables with a handful of rows (nav / token types) would take thousands of global atomics on the same few rows:
-  // their gradient is summed in LDS and leaves once per workgroup
+  const int H = a.H, F = a.F, nv = NV, HS = H + 4;
+  float* slab = lds;                                 // [WPB][H] cross-wave reduction slab
+  float* WT = lds + WPB * H;                         // [F][HS] forward weight, transposed
   const bool small1 = a.dE1 && a.E1_rows <= EMB_SMALL, small2 = a.dE2 && a.E2_rows <= EMB_SMALL;
-  float* tab1 = col + 6 * H;                         // [EMB_SMALL][H]
-  float* tab2 = tab1 + (small1 ? EMB_SMALL * H : 0);
-  if (a.feat)
-    for (int j = threadIdx.x; j < H * F; j += 256) {
-      const int h = j / F, k = j - h * F;
-      WT[k * HS + h] = a.Wf[j];
-      dWT[k * HS + h] = 0.f;
-    }
-  for (int j = threadIdx.x; j < (6 + (small1 ? EMB_SMALL : 0) + (small2 ? EMB_SMALL : 0)) * H; j += 256) col[j] = 0.f;
-  __syncthreads();
+  constexpr int FA = FR ? FR : 1, TA = TS ? EMB_SMALL : 1, TB = TS > 1 ? EMB_SMALL : 1;
+  float4 a_bf[NV], a_lfg[NV], a_lfb[NV], a_vec[NV], a_log[NV], a_lob[NV], a_w[FA][NV], a_t1[TA][NV], a_t2[TB][NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    a_bf[i] = a_lfg[i] = a_lfb[i] = a_vec[i] = a_log[i] = a_lob[i] = f4(0.f);
+#pragma unroll
+    for (int k = 0; k < FA; ++k) a_w[k][i] = f4(0.f);
+#pragma unroll
+    for (int r = 0; r < TA; ++r) a_t1[r][i] = f4(0.f);
+#pragma unroll
+    for (int r = 0; r < TB; ++r) a_t2[r][i] = f4(0.f);
+  }
+  if (FR && a.feat) {
+    stage_wt<256>(WT, a.Wf, H, F, HS, threadIdx.x);
+    __syncthreads();
+  }
   const T* base = reinterpret_cast<const T*>(a.base);
   const T* dout = reinterpret_cast<const T*>(a.dout);
   T* dbase = reinterpret_cast<T*>(a.dbase);
   const int m0 = blockIdx.x * rows_per_block, m1 = min(a.M, m0 + rows_per_block);
   for (int row = m0 + wave; row < m1; row += WPB) {
-    float f[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) f[k] = (a.feat && k < F) ? a.feat[(size_t)row * a.ldf + k] : 0.f;
+    // the row's features: ONE load (lane k holds feature k), then broadcasts - F conditional loads in a row were F memory
+    // latencies in a row
+    const float fl = (FR && a.feat) ? a.feat[(size_t)row * a.ldf + min(lane, F - 1)] : 0.f;
     const int i1 = a.E1 ? embed_index_b(a.idx1, a.idx1_kind, a.idx1_stride, a.idx1_div, row) : 0;
     const int i2 = a.E2 ? embed_index_b(a.idx2, a.idx2_kind, a.idx2_stride, a.idx2_div, row) : 0;
     float4 zf[MAXV], z[MAXV], g[MAXV];
     float rstd_f = 1.f, rstd_o = 1.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) zf[i] = z[i] = g[i] = f4(0.f);
-    if (a.feat) {
+    // every global load of the row first
 #pragma unroll
-      ROWV(i, c) {
+    ROWN(i, c) {
+      g[i] = ld4(dout + (size_t)row * a.lddo + c);
+      if (base) z[i] = ld4(base + (size_t)row * a.ldb + c);
+    } ENDV
+    if (a.lno_gamma) {                                   // the forward sum is only needed to redo the output LayerNorm
+      if (a.E1) {
+#pragma unroll
+        ROWN(i, c) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c); ENDV
+      }
+      if (a.E2) {
+#pragma unroll
+        ROWN(i, c) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c); ENDV
+      }
+      if (a.vec) {
+#pragma unroll
+        ROWN(i, c) z[i] = z[i] + *reinterpret_cast<const float4*>(a.vec + c); ENDV
+      }
+    }
+    float f[FA];
+#pragma unroll
+    for (int k = 0; k < FA; ++k) f[k] = k < F ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fl), k)) : 0.f;
+    if (FR && a.feat) {
+#pragma unroll
+      ROWN(i, c) {
         float4 o = a.bf ? *reinterpret_cast<const float4*>(a.bf + c) : f4(0.f);
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < FA; ++k)
           if (k < F) o = o + f[k] * *reinterpret_cast<const float4*>(&WT[k * HS + c]);
         zf[i] = o;
       } ENDV
       if (a.lnf_gamma) {
         rstd_f = ln_hat(zf, nv, lane, H, a.eps);
 #pragma unroll
-        ROWV(i, c) z[i] = zf[i] * *reinterpret_cast<const float4*>(a.lnf_gamma + c) + *reinterpret_cast<const float4*>(a.lnf_beta + c); ENDV
+        ROWN(i, c) z[i] = z[i] + zf[i] * *reinterpret_cast<const float4*>(a.lnf_gamma + c) + *reinterpret_cast<const float4*>(a.lnf_beta + c); ENDV
       } else {
 #pragma unroll
-        ROWV(i, c) z[i] = zf[i]; ENDV
+        ROWN(i, c) z[i] = z[i] + zf[i]; ENDV
       }
     }
-#pragma unroll
-    ROWV(i, c) {
-      if (base) z[i] = z[i] + ld4(base + (size_t)row * a.ldb + c);
-      if (a.E1) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + c);
-      if (a.E2) z[i] = z[i] + *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + c);
-      if (a.vec) z[i] = z[i] + *reinterpret_cast<const float4*>(a.vec + c);
-      g[i] = ld4(dout + (size_t)row * a.lddo + c);
-    } ENDV
     if (a.lno_gamma) {
       rstd_o = ln_hat(z, nv, lane, H, a.eps);            // z <- normalised row
 #pragma unroll
-      ROWV(i, c) {
-        lds_add4(col + 4 * H + c, g[i] * z[i]);
-        lds_add4(col + 5 * H + c, g[i]);
+      ROWN(i, c) {
+        a_log[i] = a_log[i] + g[i] * z[i];
+        a_lob[i] = a_lob[i] + g[i];
         g[i] = g[i] * *reinterpret_cast<const float4*>(a.lno_gamma + c);
       } ENDV
       ln_dz(g, z, rstd_o, nv, lane, H);
     }
     // g = dz: gradient of the pre-LayerNorm sum
 #pragma unroll
-    ROWV(i, c) {
+    ROWN(i, c) {
       if (dbase) st4(dbase + (size_t)row * a.lddb + c, g[i]);
-      if (small1) lds_add4(tab1 + i1 * H + c, g[i]);
-      else if (a.dE1) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics (generic atomicAdd)
-      if (small2) lds_add4(tab2 + i2 * H + c, g[i]);
-      else if (a.dE2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
-      if (a.vec) lds_add4(col + 3 * H + c, g[i]);
+      if (a.dE1 && !small1 && i1 != a.E1_padding_idx) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics
+      if (a.dE2 && !small2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
     } ENDV
-    if (a.feat) {
+    if constexpr (TS > 0) {                              // the row's table index is wave-uniform: a scalar branch per slot
+      if (small1) {
+#pragma unroll
+        for (int r = 0; r < TA; ++r)
+          if (i1 == r) {
+#pragma unroll
+            ROWN(i, c) a_t1[r][i] = a_t1[r][i] + g[i]; ENDV
+          }
+      }
+    }
+    if constexpr (TS > 1) {
+      if (small2) {
+#pragma unroll
+        for (int r = 0; r < TB; ++r)
+          if (i2 == r) {
+#pragma unroll
+            ROWN(i, c) a_t2[r][i] = a_t2[r][i] + g[i]; ENDV
+          }
+      }
+    }
+    if (a.vec) {
+#pragma unroll
+      ROWN(i, c) a_vec[i] = a_vec[i] + g[i]; ENDV
+    }
+    if (FR && a.feat) {
       if (a.lnf_gamma) {
 #pragma unroll
-        ROWV(i, c) {
-          lds_add4(col + 1 * H + c, g[i] * zf[i]);
-          lds_add4(col + 2 * H + c, g[i]);
+        ROWN(i, c) {
+          a_lfg[i] = a_lfg[i] + g[i] * zf[i];
+          a_lfb[i] = a_lfb[i] + g[i];
           g[i] = g[i] * *reinterpret_cast<const float4*>(a.lnf_gamma + c);
         } ENDV
         ln_dz(g, zf, rstd_f, nv, lane, H);
       }
 #pragma unroll
-      ROWV(i, c) {
-        lds_add4(col + c, g[i]);
+      ROWN(i, c) {
+        a_bf[i] = a_bf[i] + g[i];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < F) lds_add4(&dWT[k * HS + c], f[k] * g[i]);
+        for (int k = 0; k < FA; ++k)
+          if (k < F) a_w[k][i] = a_w[k][i] + f[k] * g[i];
       } ENDV
     }
   }
-  __syncthreads();
-  if (a.feat) {
-    for (int j = threadIdx.x; j < H * F; j += 256) {
-      const int h = j / F, k = j - h * F;
-      atomicAdd(a.dWf + j, dWT[k * HS + h]);
-    }
-    if (a.dbf) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dbf + c, col[c]);
-    if (a.lnf_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlnf_gamma + c, col[H + c]); atomicAdd(a.dlnf_beta + c, col[2 * H + c]); }
+  // the four waves' register sums -> one global atomic per element per workgroup.  `on` and the loop bounds are
+  // workgroup-uniform, so every thread reaches the barriers.
+  auto flush = [&](const float4 (&acc)[NV], float* dst, int dst_stride, bool on) {
+    if (!on) return;
+    // LDS-only barriers: __syncthreads() also waits for the previous vector's global atomics (a ~2.5 us round trip per
+    // flush, 10-20 flushes per workgroup)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    ROWN(i, c) *reinterpret_cast<float4*>(slab + wave * H + c) = acc[i]; ENDV
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int c = threadIdx.x; c < H; c += 256)
+      atomicAdd(dst + (size_t)c * dst_stride, (slab[c] + slab[H + c]) + (slab[2 * H + c] + slab[3 * H + c]));
+  };
+  if (FR && a.feat) {
+#pragma unroll
+    for (int k = 0; k < FA; ++k) flush(a_w[k], a.dWf + k, F, k < F);
+    flush(a_bf, a.dbf, 1, a.dbf != nullptr);
+    flush(a_lfg, a.dlnf_gamma, 1, a.lnf_gamma != nullptr);
+    flush(a_lfb, a.dlnf_beta, 1, a.lnf_gamma != nullptr);
   }
-  if (small1) for (int c = threadIdx.x; c < a.E1_rows * H; c += 256) atomicAdd(a.dE1 + c, tab1[c]);
-  if (small2) for (int c = threadIdx.x; c < a.E2_rows * H; c += 256) atomicAdd(a.dE2 + c, tab2[c]);
-  if (a.vec) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(a.dvec + c, col[3 * H + c]);
-  if (a.lno_gamma) for (int c = threadIdx.x; c < H; c += 256) { atomicAdd(a.dlno_gamma + c, col[4 * H + c]); atomicAdd(a.dlno_beta + c, col[5 * H + c]); }
+  if constexpr (TS > 0) {
+#pragma unroll
+    for (int r = 0; r < TA; ++r) flush(a_t1[r], a.dE1 + (size_t)r * H, 1, small1 && r < a.E1_rows);
+  }
+  if constexpr (TS > 1) {
+#pragma unroll
+    for (int r = 0; r < TB; ++r) flush(a_t2[r], a.dE2 + (size_t)r * H, 1, small2 && r < a.E2_rows);
+  }
+  flush(a_vec, a.dvec, 1, a.vec != nullptr);
+  flush(a_log, a.dlno_gamma, 1, a.lno_gamma != nullptr);
+  flush(a_lob, a.dlno_beta, 1, a.lno_gamma != nullptr);
 }
+#undef ROWN
 
 // ---- segment-weighted row gather (pre-training trajectory aggregation, PT/model/vilmodel.py:557-571, 597-635):
 //   out[r, :] = sum_{e in [seg_ptr[r], seg_ptr[r+1])} w[e] * in[idx[e], :]
@@ -536,20 +599,33 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   DSRG_CHECK(al(a.dout, m) && al(a.base, m) && al(a.dbase, m) && al(a.E1, 15) && al(a.E2, 15) && al(a.vec, 15) && al(a.bf, 15) && al(a.lnf_gamma, 15) &&
                  al(a.lnf_beta, 15) && al(a.lno_gamma, 15) && al(a.lno_beta, 15), "dsrg_embed_ln_bwd: misaligned pointer");
   if (a.M == 0) return DSRG_OK;
-  const int rpb = strip(a.M);
+  // ~256 workgroups: with the column sums in registers a longer strip per wave means fewer LDS / global atomics
+  // ~256 workgroups (measured best for 4932 rows: 89 us, against 111 us with ~512 and 98 us with ~128): a longer strip per
+  // wave means fewer same-address global atomics at the end, a shorter one more rows in flight
+  const int rpb0 = ((a.M + 255) / 256 + WPB - 1) / WPB * WPB, rpb = rpb0 < WPB ? WPB : rpb0;
   DSRG_CHECK((!a.dE1 || a.E1_rows >= 1) && (!a.dE2 || a.E2_rows >= 1), "dsrg_embed_ln_bwd: table row counts missing");
-  const int nsmall = ((a.dE1 && a.E1_rows <= EMB_SMALL) ? EMB_SMALL : 0) + ((a.dE2 && a.E2_rows <= EMB_SMALL) ? EMB_SMALL : 0);
-  const size_t lds = ((a.feat ? 2 * (size_t)a.F * (a.H + 4) : 0) + (6 + nsmall) * (size_t)a.H) * sizeof(float);
-  DSRG_CHECK(lds <= 160 * 1024, "dsrg_embed_ln_bwd: F=%d, H=%d with small tables needs %zu B of LDS", a.F, a.H, lds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  const bool small1 = a.dE1 && a.E1_rows <= EMB_SMALL, small2 = a.dE2 && a.E2_rows <= EMB_SMALL;
+  const int ts = small2 ? 2 : small1 ? 1 : 0, fr = !a.feat ? 0 : a.F <= 8 ? 8 : 16;
+  const size_t lds = ((size_t)WPB * a.H + (a.feat ? (size_t)a.F * (a.H + 4) : 0)) * sizeof(float);
   dim3 grid((a.M + rpb - 1) / rpb), block(256);
-  if (a.dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), grid, block, lds, (hipStream_t)stream, a, rpb);
-  else hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, rpb);
+  hipStream_t st = (hipStream_t)stream;
+#define EMB_BWD(T, NV, FR, TS)                                                                                             \
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<T, NV, FR, TS>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((embed_ln_bwd_kernel<T, NV, FR, TS>), grid, block, lds, st, a, rpb);                                \
+  } while (0)
+#define EMB_TS(T, NV, FR) do { if (ts == 0) EMB_BWD(T, NV, FR, 0); else if (ts == 1) EMB_BWD(T, NV, FR, 1); else EMB_BWD(T, NV, FR, 2); } while (0)
+#define EMB_FR(T, NV) do { if (fr == 0) EMB_TS(T, NV, 0); else if (fr == 8) EMB_TS(T, NV, 8); else EMB_TS(T, NV, 16); } while (0)
+  if (a.H <= 768) { if (a.dtype == DSRG_F32) EMB_FR(float, 3); else EMB_FR(bf16_t, 3); }
+  else { if (a.dtype == DSRG_F32) EMB_FR(float, 4); else EMB_FR(bf16_t, 4); }
+#undef EMB_FR
+#undef EMB_TS
+#undef EMB_BWD
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_bwd");
   return DSRG_OK;
 }

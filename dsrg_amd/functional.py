@@ -419,7 +419,7 @@ class _EmbedLnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b):
-        M, H, dtype, device, idx1, idx2, eps = cfg
+        M, H, dtype, device, idx1, idx2, eps, _ = cfg
         ctx.cfg = cfg
         ctx.save_for_backward(base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
         return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, (lnf_g, lnf_b) if lnf_g is not None else None,
@@ -427,12 +427,13 @@ class _EmbedLnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        M, H, dtype, device, idx1, idx2, eps = ctx.cfg
+        M, H, dtype, device, idx1, idx2, eps, pad1 = ctx.cfg
         base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b = ctx.saved_tensors
         if feat is not None and ctx.needs_input_grad[2]:
             raise _lib.DsrgHipError('embed_ln: no gradient w.r.t. the raw feature input')
         g = K.embed_ln_bwd(M, H, dout.to(dtype), base, feat, Wf, bf, (lnf_g, lnf_b) if lnf_g is not None else None, E1, idx1, E2, idx2,
-                           vec, (lno_g, lno_b) if lno_g is not None else None, eps, need_dbase=ctx.needs_input_grad[1])
+                           vec, (lno_g, lno_b) if lno_g is not None else None, eps, need_dbase=ctx.needs_input_grad[1],
+                           E1_padding_idx=pad1)
         db = g['base']
         if db is not None and base is not None:
             db = db.view(base.shape)
@@ -440,15 +441,16 @@ class _EmbedLnFn(torch.autograd.Function):
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
-             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
-    """Token-embedding sum + LayerNorm(s) (BertEmbeddings and the four visual token sites, see include/dsrg_hip.h)."""
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, E1_padding_idx=None):
+    """Token-embedding sum + LayerNorm(s) (BertEmbeddings and the four visual token sites, see include/dsrg_hip.h).
+    E1_padding_idx: row of E1 that receives no gradient (the word table is nn.Embedding(padding_idx=0) in the reference)."""
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
     ts = (base, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
     if _needs_grad(ts):
         if base is not None and base.dim() != 2:
             base = base.reshape(M, H)
-        return _EmbedLnFn.apply((M, H, dtype, device, idx1, idx2, eps), base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
+        return _EmbedLnFn.apply((M, H, dtype, device, idx1, idx2, eps, E1_padding_idx), base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
     return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out)
 
 

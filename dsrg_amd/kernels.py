@@ -537,8 +537,9 @@ def igl_blend_bwd(aug, x, wa, ba, wo, bo, dout):
 
 
 def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None, E2=None, idx2=None,
-                 vec=None, lno=None, eps=1e-12, need_dbase=True):
-    """Backward of embed_ln -> dict with the gradients of the terms that are present (fp32, table gradients dense)."""
+                 vec=None, lno=None, eps=1e-12, need_dbase=True, E1_padding_idx=None):
+    """Backward of embed_ln -> dict with the gradients of the terms that are present (fp32, table gradients dense).
+    E1_padding_idx: row of E1 that gets no gradient (nn.Embedding's padding_idx)."""
     lib = _lib.load()
     dout = rows_ok(dout)
     _dev(dout)
@@ -561,6 +562,7 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
     a.idx1_kind, a.idx1_stride, a.idx1_div, a.idx2_kind, a.idx2_stride, a.idx2_div = k1, s1, d1, k2, s2, d2
     a.lddo, a.lddb, a.M, a.H, a.dtype, a.eps = _rows(dout)[1], H, M, H, _dt(dout), float(eps)
     a.E1_rows, a.E2_rows = (E1.shape[0] if E1 is not None else 0), (E2.shape[0] if E2 is not None else 0)
+    a.E1_padding_idx = -1 if E1_padding_idx is None else int(E1_padding_idx)
     _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
     return g
 

@@ -401,7 +401,7 @@ class GlocalTextPathNavCMT(nn.Module):
         pos = torch.arange(L, device=txt_ids.device, dtype=torch.int32).repeat(B)
         x = Fn.embed_ln(B * L, H, cd, txt_ids.device, E1=W['emb.word'], idx1=txt_ids.reshape(-1),
                         E2=W['emb.pos'], idx2=pos, vec=W['emb.type'][0], lno=(W['emb.ln.g'], W['emb.ln.b']),
-                        eps=cfg.layer_norm_eps).view(B, L, H)
+                        eps=cfg.layer_norm_eps, E1_padding_idx=self.embeddings.word_embeddings.padding_idx).view(B, L, H)
         x = self._drop(x, cfg.hidden_dropout_prob)
         tm = txt_masks.contiguous()
         for i in range(cfg.num_l_layers):

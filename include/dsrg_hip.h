@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 5
+#define DSRG_ABI_VERSION 6
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -316,7 +316,9 @@ typedef struct {
   float* dlno_gamma; float* dlno_beta;
   int32_t ldb, ldf, F, idx1_kind, idx1_stride, idx1_div, idx2_kind, idx2_stride, idx2_div, lddo, lddb, M, H, dtype;
   float eps;
-  int32_t E1_rows, E2_rows;   /* rows of the tables (tables of <= 4 rows are summed in LDS first) */
+  int32_t E1_rows, E2_rows;   /* rows of the tables (tables of <= 4 rows are summed in registers first) */
+  int32_t E1_padding_idx;     /* row of E1 that receives no gradient, as nn.Embedding(padding_idx=0) of the reference's
+                               * word embeddings (finetune_src/models/vilmodel.py:65); -1 = none */
 } dsrg_embed_bwd_args_t;
 int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
 

@@ -145,7 +145,7 @@ def forward_text(sd, cfg, b, reverie=False):
     """FT/vilmodel.py:678-688, 76-96, 509-530 (REVERIE IGL: vilmodel_reverie.py:523-529)."""
     ids = b['txt_ids']
     L = ids.shape[1]
-    x = F.embedding(ids, sd['embeddings.word_embeddings.weight']) \
+    x = F.embedding(ids, sd['embeddings.word_embeddings.weight'], padding_idx=0) \
         + sd['embeddings.position_embeddings.weight'][:L][None] \
         + sd['embeddings.token_type_embeddings.weight'][0][None, None]
     x = ln(sd, 'embeddings.LayerNorm', x, cfg.layer_norm_eps)

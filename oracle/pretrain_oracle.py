@@ -20,7 +20,7 @@ class _Sub(dict):
 def text(sd, cfg, b):  # PT/vilmodel.py:738-748, 79-100 (IGL branch unreachable: collators pass act_txt_ids=None)
     ids = b['txt_ids']
     L = ids.shape[1]
-    x = F.embedding(ids, sd['embeddings.word_embeddings.weight']) + sd['embeddings.position_embeddings.weight'][:L][None] \
+    x = F.embedding(ids, sd['embeddings.word_embeddings.weight'], padding_idx=0) + sd['embeddings.position_embeddings.weight'][:L][None] \
         + sd['embeddings.token_type_embeddings.weight'][0][None, None]
     x = ln(sd, 'embeddings.LayerNorm', x, cfg.layer_norm_eps)
     tm = seq_masks(b['txt_lens'], L)

@@ -480,33 +480,38 @@ def test_row_op_backward_kernels(dtype):
         return gate * a + (1 - gate) * xf
     check([aug, xx, wa, ba, wo, bo], lambda: Fn.igl_blend(aug, xx, wa, ba, wo, bo), igl_ref, 'igl_blend')
     # token-embedding sums: the panorama-token form (every term present) and the text form (two tables + vector)
-    M, H, Fd = 333, 768, 7
-    base = leaf(M, H, seed=20)
-    feat = _r(M, Fd + 1, seed=21)
-    Wf, bf = leaf(H, Fd, seed=22, scale=0.3, dt=torch.float32), leaf(H, seed=23, scale=0.02, dt=torch.float32)
-    E1, E2, vec = leaf(45, H, seed=24, dt=torch.float32), leaf(3, H, seed=25, dt=torch.float32), leaf(H, seed=26, dt=torch.float32)
-    gf, bfb = leaf(H, seed=27, scale=0.1, dt=torch.float32), leaf(H, seed=28, scale=0.1, dt=torch.float32)
-    go_, bo_ = leaf(H, seed=29, scale=0.1, dt=torch.float32), leaf(H, seed=30, scale=0.1, dt=torch.float32)
-    i1 = torch.randint(0, 45, (M,)).cuda()
-    i2g = torch.randint(0, 3, ((M + 2) // 3,)).cuda()
+    for M in (333, 2500):      # one row per wave, and strips of 3 rows per wave (sums carried in registers)
+        H, Fd = 768, 7
+        base = leaf(M, H, seed=20)
+        feat = _r(M, Fd + 1, seed=21)
+        Wf, bf = leaf(H, Fd, seed=22, scale=0.3, dt=torch.float32), leaf(H, seed=23, scale=0.02, dt=torch.float32)
+        E1, E2, vec = leaf(45, H, seed=24, dt=torch.float32), leaf(3, H, seed=25, dt=torch.float32), leaf(H, seed=26, dt=torch.float32)
+        gf, bfb = leaf(H, seed=27, scale=0.1, dt=torch.float32), leaf(H, seed=28, scale=0.1, dt=torch.float32)
+        go_, bo_ = leaf(H, seed=29, scale=0.1, dt=torch.float32), leaf(H, seed=30, scale=0.1, dt=torch.float32)
+        i1 = torch.randint(0, 45, (M,)).cuda()
+        i2g = torch.randint(0, 3, ((M + 2) // 3,)).cuda()
 
-    def emb_ref():
-        t = F.layer_norm(feat[:, :Fd] @ Wf.T + bf, (H,), gf + 1, bfb, 1e-12)
-        return F.layer_norm(base.float() + t + E1[i1] + E2[i2g.repeat_interleave(3)[:M]] + vec, (H,), go_ + 1, bo_, 1e-12)
-    check([base, Wf, bf, E1, E2, vec, gf, bfb, go_, bo_],
-          lambda: Fn.embed_ln(M, H, dtype, 'cuda', base=base, feat=feat[:, :Fd], Wf=Wf, bf=bf, lnf=(gf + 1, bfb), E1=E1, idx1=i1,
-                              E2=E2, idx2=(i2g, 3), vec=vec, lno=(go_ + 1, bo_)), emb_ref, 'embed_ln/pano')
-    Ew = leaf(500, H, seed=31, dt=torch.float32)
-    ids = torch.randint(0, 500, (M,)).cuda()
-    pos = (torch.arange(M) % 80).int().cuda()
-    Ep = leaf(80, H, seed=32, dt=torch.float32)
-    check([Ew, Ep, vec, go_, bo_],
-          lambda: Fn.embed_ln(M, H, dtype, 'cuda', E1=Ew, idx1=ids, E2=Ep, idx2=pos, vec=vec, lno=(go_ + 1, bo_)),
-          lambda: F.layer_norm(Ew[ids] + Ep[pos.long()] + vec, (H,), go_ + 1, bo_, 1e-12), 'embed_ln/text')
-    f14, W14 = _r(M, 14, seed=33), leaf(H, 14, seed=34, scale=0.3, dt=torch.float32)
-    check([base, W14, bf, gf, bfb],
-          lambda: Fn.embed_ln(M, H, dtype, 'cuda', base=base, feat=f14, Wf=W14, bf=bf, lnf=(gf + 1, bfb)),
-          lambda: base.float() + F.layer_norm(f14 @ W14.T + bf, (H,), gf + 1, bfb, 1e-12), 'embed_ln/vp')
+        def emb_ref():
+            t = F.layer_norm(feat[:, :Fd] @ Wf.T + bf, (H,), gf + 1, bfb, 1e-12)
+            return F.layer_norm(base.float() + t + E1[i1] + E2[i2g.repeat_interleave(3)[:M]] + vec, (H,), go_ + 1, bo_, 1e-12)
+        check([base, Wf, bf, E1, E2, vec, gf, bfb, go_, bo_],
+              lambda: Fn.embed_ln(M, H, dtype, 'cuda', base=base, feat=feat[:, :Fd], Wf=Wf, bf=bf, lnf=(gf + 1, bfb), E1=E1, idx1=i1,
+                                  E2=E2, idx2=(i2g, 3), vec=vec, lno=(go_ + 1, bo_)), emb_ref, 'embed_ln/pano')
+        Ew = leaf(500, H, seed=31, dt=torch.float32)
+        ids = torch.randint(0, 500, (M,)).cuda()
+        pos = (torch.arange(M) % 80).int().cuda()
+        Ep = leaf(80, H, seed=32, dt=torch.float32)
+        check([Ew, Ep, vec, go_, bo_],
+              lambda: Fn.embed_ln(M, H, dtype, 'cuda', E1=Ew, idx1=ids, E2=Ep, idx2=pos, vec=vec, lno=(go_ + 1, bo_)),
+              lambda: F.layer_norm(Ew[ids] + Ep[pos.long()] + vec, (H,), go_ + 1, bo_, 1e-12), 'embed_ln/text')
+        ids0 = torch.where(pos >= 50, torch.zeros_like(ids), ids)      # padded tail: row 0 gets no gradient (padding_idx)
+        check([Ew, Ep, vec, go_, bo_],
+              lambda: Fn.embed_ln(M, H, dtype, 'cuda', E1=Ew, idx1=ids0, E2=Ep, idx2=pos, vec=vec, lno=(go_ + 1, bo_), E1_padding_idx=0),
+              lambda: F.layer_norm(F.embedding(ids0, Ew, padding_idx=0) + Ep[pos.long()] + vec, (H,), go_ + 1, bo_, 1e-12), 'embed_ln/text-pad')
+        f14, W14 = _r(M, 14, seed=33), leaf(H, 14, seed=34, scale=0.3, dt=torch.float32)
+        check([base, W14, bf, gf, bfb],
+              lambda: Fn.embed_ln(M, H, dtype, 'cuda', base=base, feat=f14, Wf=W14, bf=bf, lnf=(gf + 1, bfb)),
+              lambda: base.float() + F.layer_norm(f14 @ W14.T + bf, (H,), gf + 1, bfb, 1e-12), 'embed_ln/vp')
     # dynamic fusion + logit fusion (fp32 scores), with a fuse score and without
     if fp32:
         from dsrg_amd import synth
