@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HeadTailProblem(C.Structure):
@@ -49,7 +49,7 @@ class EmbedBwdArgs(C.Structure):
                                           'dE2', 'dvec', 'dlno_gamma', 'dlno_beta')] + \
                [(n, C.c_int32) for n in ('ldb', 'ldf', 'F', 'idx1_kind', 'idx1_stride', 'idx1_div', 'idx2_kind', 'idx2_stride',
                                          'idx2_div', 'lddo', 'lddb', 'M', 'H', 'dtype')] + [('eps', C.c_float), ('E1_rows', C.c_int32),
-                                                                                   ('E2_rows', C.c_int32), ('E1_padding_idx', C.c_int32)]
+                                                                                   ('E2_rows', C.c_int32), ('E1_padding_idx', C.c_int32), ('E1_copies', C.c_int32)]
 
 
 class GraphState(C.Structure):

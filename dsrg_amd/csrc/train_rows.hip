@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
   const T* dout = reinterpret_cast<const T*>(a.dout);
   T* dbase = reinterpret_cast<T*>(a.dbase);
   const int m0 = blockIdx.x * rows_per_block, m1 = min(a.M, m0 + rows_per_block);
+  float* dE1w = a.dE1 + (a.E1_copies > 1 ? (size_t)(blockIdx.x % a.E1_copies) * a.E1_rows * H : 0);   // this workgroup's copy
   for (int row = m0 + wave; row < m1; row += WPB) {
     // the row's features: ONE load (lane k holds feature k), then broadcasts - F conditional loads in a row were F memory
     // latencies in a row
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
 #pragma unroll
     ROWN(i, c) {
       if (dbase) st4(dbase + (size_t)row * a.lddb + c, g[i]);
-      if (a.dE1 && !small1 && i1 != a.E1_padding_idx) lds_add4(a.dE1 + (size_t)i1 * H + c, g[i]);     // global float atomics
+      if (a.dE1 && !small1 && i1 != a.E1_padding_idx) lds_add4(dE1w + (size_t)i1 * H + c, g[i]);     // global float atomics
       if (a.dE2 && !small2) lds_add4(a.dE2 + (size_t)i2 * H + c, g[i]);
     } ENDV
     if constexpr (TS > 0) {                              // the row's table index is wave-uniform: a scalar branch per slot
@@ -604,6 +605,8 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   // wave means fewer same-address global atomics at the end, a shorter one more rows in flight
   const int rpb0 = ((a.M + 255) / 256 + WPB - 1) / WPB * WPB, rpb = rpb0 < WPB ? WPB : rpb0;
   DSRG_CHECK((!a.dE1 || a.E1_rows >= 1) && (!a.dE2 || a.E2_rows >= 1), "dsrg_embed_ln_bwd: table row counts missing");
+  DSRG_CHECK(a.E1_copies >= 0 && a.E1_copies <= 1024 && (a.E1_copies <= 1 || (a.dE1 && a.E1_rows > EMB_SMALL)),
+             "dsrg_embed_ln_bwd: E1_copies=%d needs dE1 and a table of more than %d rows", a.E1_copies, EMB_SMALL);
   const bool small1 = a.dE1 && a.E1_rows <= EMB_SMALL, small2 = a.dE2 && a.E2_rows <= EMB_SMALL;
   const int ts = small2 ? 2 : small1 ? 1 : 0, fr = !a.feat ? 0 : a.F <= 8 ? 8 : 16;
   const size_t lds = ((size_t)WPB * a.H + (a.feat ? (size_t)a.F * (a.H + 4) : 0)) * sizeof(float);

@@ -563,7 +563,16 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
     a.lddo, a.lddb, a.M, a.H, a.dtype, a.eps = _rows(dout)[1], H, M, H, _dt(dout), float(eps)
     a.E1_rows, a.E2_rows = (E1.shape[0] if E1 is not None else 0), (E2.shape[0] if E2 is not None else 0)
     a.E1_padding_idx = -1 if E1_padding_idx is None else int(E1_padding_idx)
+    # a table of a few dozen rows hit by thousands of token rows (the 45 object classes): spread the same-address float
+    # atomics over 32 copies of the gradient table and sum them afterwards
+    copies = 32 if (E1 is not None and 4 < E1.shape[0] <= 256 and M >= 2048) else 1
+    if copies > 1:
+        g['E1'] = torch.zeros(copies, E1.shape[0] * H, device=dev, dtype=torch.float32)
+        a.dE1 = _p(g['E1'])
+    a.E1_copies = copies
     _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
+    if copies > 1:
+        g['E1'] = colsum(g['E1']).view(E1.shape)
     return g
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 6
+#define DSRG_ABI_VERSION 7
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -319,6 +319,9 @@ typedef struct {
   int32_t E1_rows, E2_rows;   /* rows of the tables (tables of <= 4 rows are summed in registers first) */
   int32_t E1_padding_idx;     /* row of E1 that receives no gradient, as nn.Embedding(padding_idx=0) of the reference's
                                * word embeddings (finetune_src/models/vilmodel.py:65); -1 = none */
+  int32_t E1_copies;          /* > 1: dE1 is [E1_copies][E1_rows][H] and workgroup w adds into copy w % E1_copies; the
+                               * caller sums the copies.  Spreads the same-address atomics of a table with a few dozen
+                               * rows (the 45 object classes take 14796 rows of a pre-training batch).  0 / 1 = one copy */
 } dsrg_embed_bwd_args_t;
 int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
 
