@@ -603,7 +603,10 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   // ~256 workgroups: with the column sums in registers a longer strip per wave means fewer LDS / global atomics
   // ~256 workgroups (measured best for 4932 rows: 89 us, against 111 us with ~512 and 98 us with ~128): a longer strip per
   // wave means fewer same-address global atomics at the end, a shorter one more rows in flight
-  const int rpb0 = ((a.M + 255) / 256 + WPB - 1) / WPB * WPB, rpb = rpb0 < WPB ? WPB : rpb0;
+  // (inside a pre-training step the 888-row viewpoint launch took 180 us with 222 workgroups of one row per wave: ~23
+  // flush vectors x 222 same-address atomics each; hence fewer, longer strips for the small launches)
+  const int wgs = a.M >= 4096 ? 256 : a.M >= 1024 ? 128 : 64;
+  const int rpb0 = ((a.M + wgs - 1) / wgs + WPB - 1) / WPB * WPB, rpb = rpb0 < WPB ? WPB : rpb0;
   DSRG_CHECK((!a.dE1 || a.E1_rows >= 1) && (!a.dE2 || a.E2_rows >= 1), "dsrg_embed_ln_bwd: table row counts missing");
   DSRG_CHECK(a.E1_copies >= 0 && a.E1_copies <= 1024 && (a.E1_copies <= 1 || (a.dE1 && a.E1_rows > EMB_SMALL)),
              "dsrg_embed_ln_bwd: E1_copies=%d needs dE1 and a table of more than %d rows", a.E1_copies, EMB_SMALL);

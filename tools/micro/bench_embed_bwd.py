@@ -1,7 +1,12 @@
 """GPU box: time dsrg_embed_ln_bwd alone on the four shapes of a pre-training step (text / panorama / graph-map / viewpoint
 tokens) and on variants that isolate one cost (duplicate table rows, feature width)."""
+import os
+import sys
+
 import torch
-from dsrg_amd import kernels as K
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+from dsrg_amd import kernels as K  # noqa: E402
 
 H = 768
 dev = 'cuda'
