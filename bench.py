@@ -277,6 +277,48 @@ def pretrain_cpu_baseline(cfg, sd, budget_s=25.0):
             'sample': '%d forward+backward steps of %d trajectories (no optimiser step, fp32, %d threads), %.1f s' % (it, Bc, cores, dt)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what `python -m torch.distributed.run --nproc-per-node N` would do;
+    the reference launches its ranks the same way, pretrain_src/run_r2r.sh:8-15).  The parent never touches the GPU;
+    rank 0's stdout (the one JSON line) is forwarded; any failing child fails the run."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT') or str(_free_port()),
+               LOCAL_WORLD_SIZE=str(n))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit('bench.py: rank exit codes %s' % rcs)
+
+
+def spawn_selftest(rank, world):
+    """Launch plumbing only (tests/test_dist_gloo.py, no GPU needed): rendezvous over gloo, one all-reduce, rank 0 prints
+    the line's launch fields."""
+    dist.init_process_group('gloo')
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    assert int(t.item()) == world
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'ranks_seen': int(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -289,8 +331,16 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'RANK' not in os.environ and a.gpus > 1:
+        return spawn_ranks(a.gpus)            # before anything touches the GPU: the children are fresh processes
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, world))
+    if os.environ.get('DSRG_BENCH_SPAWN_SELFTEST') == '1':
+        return spawn_selftest(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the DSRG hot path has no CPU fallback')
     # rehearsal aid (one-GPU box): DSRG_BENCH_BACKEND=gloo runs the N ranks on the visible device(s) round-robin

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/dsrg_hip.h"
 
 typedef uint16_t bf16_t;  // raw bf16 bits
@@ -97,6 +98,18 @@ __device__ __forceinline__ float gelu_erf_short(float x) {
 
 // host side
 void dsrg_set_error(const char* fmt, ...);
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (call site, device) under std::call_once: the entry points are
+// re-entrant (include/dsrg_hip.h), and the attribute belongs to each device's copy of the code object
+#define DSRG_MAX_DEVICES 16
+#define DSRG_SET_MAX_LDS_ONCE(fn_ptr, bytes)                                                                         \
+  do {                                                                                                               \
+    static std::once_flag once_[DSRG_MAX_DEVICES];                                                                   \
+    int dev_ = 0;                                                                                                    \
+    (void)hipGetDevice(&dev_);                                                                                       \
+    auto set_ = [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }; \
+    if (dev_ >= 0 && dev_ < DSRG_MAX_DEVICES) std::call_once(once_[dev_], set_);                                     \
+    else set_();                                                                                                     \
+  } while (0)
 #define DSRG_CHECK(cond, ...)                 \
   do {                                        \
     if (!(cond)) {                            \

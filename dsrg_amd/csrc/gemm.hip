@@ -382,17 +382,23 @@ template <typename T, typename OutT, int BM, int BN, int NST>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
   constexpr int smem = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, OutT, BM, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST>), smem);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST>), dim3(total_tiles), dim3(256), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
   return DSRG_OK;
 }
 
-int g_nst_override = 0;
+// DSRG_GEMM_TILE="BMxBN[xNST]" (tuning aid), parsed once (thread-safe function-local static), read-only afterwards
+struct TileOverride { int bm, bn, nst; bool set; };
+const TileOverride& tile_override() {
+  static const TileOverride o = [] {
+    TileOverride t{0, 0, 0, false};
+    const char* force = getenv("DSRG_GEMM_TILE");     // "128x128" | "64x128" | "64x64" [x ring depth]
+    if (force && sscanf(force, "%dx%dx%d", &t.bm, &t.bn, &t.nst) >= 2) t.set = true;
+    return t;
+  }();
+  return o;
+}
 
 // tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
 int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
@@ -407,9 +413,9 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
   };
   int maxM = 0;
   for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
-  static const char* force = getenv("DSRG_GEMM_TILE");     // tuning aid: "128x128" | "64x128" | "64x64"
-  if (force && sscanf(force, "%dx%dx%d", &bm, &bn, &g_nst_override) >= 2 && ((bm == 256 && (bn == 128 || bn == 192)) || (bm == 128 && bn == 192) || ((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && !(bm == 128 && bn == 64))))
-{
+  const TileOverride& ov = tile_override();
+  if (ov.set && ((ov.bm == 256 && (ov.bn == 128 || ov.bn == 192)) || (ov.bm == 128 && ov.bn == 192) || ((ov.bm == 128 || ov.bm == 64) && (ov.bn == 128 || ov.bn == 64) && !(ov.bm == 128 && ov.bn == 64)))) {
+    bm = ov.bm; bn = ov.bn;
     bool ok = big_ok || !(bm == 256 || bn == 192);      // the wide tiles exist for bf16 only
 #ifndef DSRG_GEMM_BIG_TILES
     if (bm == 256) ok = false;
@@ -461,7 +467,7 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
   // Ring depth: 2 keeps the most workgroups per CU and wins whenever a CU holds >= 2 tiles; with <= ~1.7 tiles per CU
   // and a long K loop (the FFN-out projections of the panorama / object encoders) a lone workgroup cannot cover the
   // L2 latency with one stage in flight, and a 3-deep ring is 17-30 % faster (tools/bench_gemm.py).
-  int nst = g_nst_override;
+  int nst = tile_override().set ? tile_override().nst : 0;
   if (nst == 0 && bm == 64 && bn == 64 && tiles <= 512) {
     int minK = 1 << 30;
     for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;

@@ -570,12 +570,8 @@ extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, i
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + EWAVES - 1) / EWAVES), block(64 * EWAVES);
   const size_t lds = feat ? (size_t)F * (H + 4) * sizeof(float) : 0;     // <= 16 * 1028 * 4 = 65,792 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024);
-    attr_set = true;
-  }
+  DSRG_SET_MAX_LDS_ONCE(&embed_ln_kernel<float>, 66 * 1024);
+  DSRG_SET_MAX_LDS_ONCE(&embed_ln_kernel<bf16_t>, 66 * 1024);
   if (dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_kernel<float>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((embed_ln_kernel<bf16_t>), grid, block, lds, s, a);
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_fwd");
@@ -601,12 +597,8 @@ extern "C" int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bia
   DSRG_CHECK(al16(x) && al16(out) && al16(w), "dsrg_gaa_pool_fwd: misaligned pointer");
   if (B <= 0) return DSRG_OK;
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {     // 16 x 1024 floats + the score vector is just over the 64 KiB default
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gaa_pool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gaa_pool_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
-  }
+  DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<float>, 65536);     // 16 x 1024 floats + the score vector is just over the 64 KiB default
+  DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<bf16_t>, 65536);
   if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, w, bias, (float*)out, V, H);
   else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, w, bias, (bf16_t*)out, V, H);
   DSRG_LAUNCH_CHECK("dsrg_gaa_pool_fwd");

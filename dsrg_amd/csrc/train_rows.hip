@@ -617,12 +617,7 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   hipStream_t st = (hipStream_t)stream;
 #define EMB_BWD(T, NV, FR, TS)                                                                                             \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_ln_bwd_kernel<T, NV, FR, TS>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                    \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    DSRG_SET_MAX_LDS_ONCE((&embed_ln_bwd_kernel<T, NV, FR, TS>), 96 * 1024);                                               \
     hipLaunchKernelGGL((embed_ln_bwd_kernel<T, NV, FR, TS>), grid, block, lds, st, a, rpb);                                \
   } while (0)
 #define EMB_TS(T, NV, FR) do { if (ts == 0) EMB_BWD(T, NV, FR, 0); else if (ts == 1) EMB_BWD(T, NV, FR, 1); else EMB_BWD(T, NV, FR, 2); } while (0)

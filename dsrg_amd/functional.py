@@ -254,11 +254,12 @@ def linear_grouped(problems, act=ACT_NONE, out_f32=False):
         return K.gemm(problems, act, out_f32)
     if act != ACT_NONE and any(p[3] is not None for p in problems):
         raise _lib.DsrgHipError('linear_grouped: activation together with a residual is not used on this path')
-    zs = _LinearFn.apply(len(problems), out_f32 and act == ACT_NONE, *flat)
+    # out_f32: the pre-activation stays fp32 and the activation runs on it, as the fused epilogue of the no-grad path
+    # does on the fp32 accumulator (train-mode and eval-mode head scores then agree)
+    zs = _LinearFn.apply(len(problems), out_f32, *flat)
     if act == ACT_NONE:
         return list(zs)
-    ys = [activation(z, act) for z in zs]
-    return [y.float() for y in ys] if out_f32 else ys
+    return [activation(z, act) for z in zs]
 
 
 def linear(x, w, b=None, act=ACT_NONE, residual=None, out_f32=False):

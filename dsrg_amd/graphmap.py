@@ -139,6 +139,11 @@ class BatchedGraphMap:
             out.append([None, None] + [v for s, v in enumerate(nm) if s in vis] + [v for s, v in enumerate(nm) if s not in vis])
         return out
 
+    def current_token_index(self, nav):
+        """int64 [B]: position of each episode's current node in the graph-map token order of `nav` (= nav_inputs() output);
+        what GraphedNavStep.set_current_node() takes"""
+        return (nav['gmap_slots'] == self._cur['cur'][:, None]).int().argmax(1)
+
     def nav_inputs(self, pano_embeds, nav_types, view_lens, last_embeds=None):
         """_nav_gmap_variable + _nav_vp_variable (agent.py:157-278) -> the dict forward(mode='navigation') takes (plus the device-side
         fusion indices `gmap_src` / `bw_mask`, so the model's forward does no host work)."""

@@ -126,6 +126,13 @@ def gemm_replay(rec):
     _lib.check(_lib.load().dsrg_gemm_nt(rec['arr'], rec['n'], rec['dt'], rec['odt'], rec['act'], _stream()), 'dsrg_gemm_nt')
 
 
+def _check_heads(nh, *ts):
+    """the attention kernels are built for head dim 64: every operand must be [.., .., nh*64]"""
+    for t in ts:
+        if t.dim() != 3 or t.shape[2] != nh * 64:
+            raise _lib.DsrgHipError('attention: operand %s is not [B, N, nh*64] with nh=%d (head dim must be 64)' % (tuple(t.shape), nh))
+
+
 def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125,
               want_lse=False, p_drop=0.0, seed=0):
     """q [B,Nq,nh*64], k/v [B,Nk,nh*64] views (row/batch strides free, last dim contiguous)."""
@@ -136,6 +143,7 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     for t in (q, k, v):
         if t.stride(2) != 1 or t.dtype != q.dtype:
             raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes equal')
+    _check_heads(nh, q, k, v)
     out = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
     if kmask is not None:
         if kmask.dtype != torch.bool or kmask.shape != (B, Nk) or not kmask.is_contiguous():
@@ -168,6 +176,7 @@ def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, spre
         for t in (q, k, v):
             if t.stride(2) != 1 or t.dtype != q0.dtype or t.shape[0] != B:
                 raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes and batch equal')
+        _check_heads(nh, q, k, v)
         if kmask is not None and (kmask.dtype != torch.bool or kmask.shape != (B, Nk) or not kmask.is_contiguous()):
             raise _lib.DsrgHipError('attention: kmask must be contiguous bool [B,Nk]')
         if (kmask is None) != (mask_mode == _lib.MASK_NONE):
@@ -192,6 +201,7 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     lib = _lib.load()
     B, Nq, _ = q.shape
     Nk = k.shape[1]
+    _check_heads(nh, q, k, v, o, do)
     do = do if do.stride(2) == 1 else do.contiguous()
     dq = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
     dk = torch.empty(B, Nk, nh * 64, device=q.device, dtype=q.dtype)

@@ -30,6 +30,34 @@ def get_vlnbert_models(args, config=None, state_dict=None, compute_dtype=None):
     return GlocalTextPathNavCMT.from_pretrained(None, config=cfg, state_dict=new_sd, **kw)
 
 
+def load_agent_checkpoint(models, path, strict_shapes=True):
+    """Counterpart of Seq2SeqAgent.load (finetune_src/r2r/agent_base.py:242-274) for the parameter part: `models` maps the
+    snapshot's names ('vln_bert', 'critic') to modules; keys are matched tolerantly (a 'module.' prefix on either side is
+    fixed, extra keys in the file are reported and skipped, keys missing from the file keep the module's values).  The file
+    is read with weights_only=True.  Returns (epoch - 1, {name: [extra keys]}) like the reference returns the epoch."""
+    states = torch.load(path, map_location='cpu', weights_only=True)
+    extra = {}
+    for name, model in models.items():
+        state = model.state_dict()
+        model_keys = set(state.keys())
+        sd = states[name]['state_dict']
+        if model_keys != set(sd.keys()):
+            mk0, lk0 = next(iter(model_keys)), next(iter(sd.keys()))
+            if not mk0.startswith('module.') and lk0.startswith('module.'):
+                sd = {k.replace('module.', ''): v for k, v in sd.items()}
+            if mk0.startswith('module.') and not lk0.startswith('module.'):
+                sd = {'module.' + k: v for k, v in sd.items()}
+            extra[name] = [k for k in sd if k not in model_keys]
+            sd = {k: v for k, v in sd.items() if k in model_keys}
+        if strict_shapes:
+            bad = [k for k, v in sd.items() if tuple(v.shape) != tuple(state[k].shape)]
+            if bad:
+                raise ValueError('load_agent_checkpoint: size mismatch for %s' % ', '.join(bad[:8]))
+        state.update(sd)
+        model.load_state_dict(state)
+    return states['vln_bert']['epoch'] - 1, extra
+
+
 class VLNBert(nn.Module):
     def __init__(self, args, compute_dtype=None):
         super().__init__()

@@ -6,13 +6,30 @@ the caller copies the step's inputs into `.pano` / `.nav` buffers (or writes the
 `set_text()` once per episode (recomputes the hoisted text K/V panel) and `step()` per time step.
 The agent-side glue that the reference does between the two calls (agent.py:231-237: [stop],[MEM] + panorama
 tokens -> vp_img_embeds; current node's graph-map embedding = GAA-pooled panorama, agent.py:443-447) is part
-of the captured step, and the RMF memory (cls_embeds) is fed back into the [MEM] slots for the next step."""
+of the captured step, and the RMF memory (cls_embeds) is fed back into the [MEM] slots for the next step.
+
+Graph-map token order is [stop], [MEM], visited nodes in insertion order, unvisited nodes (agent.py:165-187), so the
+CURRENT node's token is slot 2 only on the first step of an episode; `cur_gmap_idx` (int64 [B], a static buffer the
+caller updates with `set_current_node`, e.g. from BatchedGraphMap's slot table) says where the pooled panorama goes.
+
+`split=True` captures the two calls as two graphs (`pano_step()`, `nav_step()`) so that a device-resident graph map
+(dsrg_amd.graphmap.BatchedGraphMap: update_embeds -> nav_inputs, agent.py:443-468) can run between them on this
+step's panorama; `load_nav()` pads its output into the static buffers.  That is the exact rollout protocol; the
+single-graph `step()` is the serving shortcut in which only the current node's embedding changes inside the step.
+
+The captured graph holds raw addresses of the model's packed weights.  The runner keeps those tensors alive and
+re-captures when the model re-packs them (eval() / train() / .to() / load_state_dict() / an optimizer step)."""
 import torch
+
+from ._lib import DsrgHipError
 
 
 class GraphedNavStep:
-    def __init__(self, model, txt_embeds, txt_masks, pano_batch, nav_batch, use_graph=True, reverie=False):
-        self.model, self.reverie = model, reverie
+    NAV_KEYS = ('gmap_step_ids', 'gmap_pos_fts', 'gmap_masks', 'gmap_pair_dists', 'gmap_visited_masks', 'vp_pos_fts', 'vp_masks',
+                'vp_nav_masks', 'vp_obj_masks', 'gmap_src', 'bw_mask')
+
+    def __init__(self, model, txt_embeds, txt_masks, pano_batch, nav_batch, use_graph=True, reverie=False, split=False):
+        self.model, self.reverie, self.split = model, reverie, split
         dev = txt_embeds.device
         self.txt = txt_embeds.clone()
         self.txt_masks = txt_masks.clone()
@@ -25,58 +42,164 @@ class GraphedNavStep:
             self.nav['gmap_src'], self.nav['bw_mask'] = torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev)
         H, cd = model.config.hidden_size, model.compute_dtype
         # static compute-dtype token buffers of the navigation call: slot 1 = [MEM] (fed back from cls_embeds), graph-map
-        # slot 2 = the current node (GAA-pooled panorama), viewpoint slots 2.. = this step's panorama tokens
+        # slot cur_gmap_idx = the current node (GAA-pooled panorama), viewpoint slots 2.. = this step's panorama tokens
         self.gmap_img = self.nav['gmap_img_embeds'].to(cd).clone()
         self.vp_img = torch.zeros(B, Vp, H, device=dev, dtype=cd)
         self.gmap_img[:, 1].zero_()
+        self.cur_gmap_idx = torch.full((B,), 2, device=dev, dtype=torch.int64)
+        self._rows = torch.arange(B, device=dev)
+        self.use_graph = use_graph
+        self.out, self.pano_out = None, None
+        self.graph = self.graph_pano = self.graph_nav = None
+        self._capture()
+
+    def _capture(self):
+        """(Re)build everything that bakes in the packed weights' addresses: the text K/V panel and the HIP graph(s)."""
+        model = self.model
         with torch.no_grad():
-            self.kv = model.text_kv(self.txt)
-        self.out = None
-        self.graph = None
-        if use_graph:
+            self._W = model._weights()            # keep the pack alive: the graphs replay raw pointers into it
+            self._token = model._wplan_token()
+            self._wver = self._pack_version()
+            self.kv = model.text_kv(self.txt) if getattr(self, 'kv', None) is None else model.text_kv(self.txt, out=self.kv)
+        self.graph = self.graph_pano = self.graph_nav = None
+        if not self.use_graph:
+            return
+        # capture leaves the recurrent state ([MEM] slots) as it found it: warm-up and capture run the body for real
+        keep = (self.vp_img[:, 1].clone(), self.gmap_img.clone())
+
+        def cap(fn):
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s), torch.no_grad():
                 for _ in range(2):
-                    self._body()
+                    fn()
             torch.cuda.current_stream().wait_stream(s)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph), torch.no_grad():
-                self._body()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                fn()
+            return g
+        if self.split:
+            self.graph_pano = cap(self._pano_body)
+            self.graph_nav = cap(self._nav_body)
+        else:
+            self.graph = cap(self._body)
+        with torch.no_grad():
+            self.vp_img[:, 1] = keep[0]
+            self.gmap_img.copy_(keep[1])
+
+    def _pack_version(self):
+        plan = self.model._wplan
+        return None if plan is None else tuple(p._version for p in plan[1].srcs)
+
+    def _check_weights(self):
+        """The model dropped or re-packed its weight cache since capture -> capture again (cheap next to serving stale
+        or freed weights silently)."""
+        m = self.model
+        # eval(): the model itself treats its pack as frozen until train()/eval()/.to()/load_state_dict() (all of which
+        # change the token); in train() mode an optimizer step may have moved the parameters: compare their versions
+        if m._wplan_token() is not self._token or m._wcache is not self._W or (m.training and self._pack_version() != self._wver):
+            if torch.cuda.is_current_stream_capturing():
+                raise DsrgHipError('GraphedNavStep: model weights changed while a capture is in progress')
+            self._capture()
 
     def set_text(self, txt_embeds, txt_masks):
         """New episode batch: copy the instruction encoding in, recompute the text K/V panel, clear [MEM]."""
+        self._check_weights()
         with torch.no_grad():
             self.txt.copy_(txt_embeds)
             self.txt_masks.copy_(txt_masks)
             self.model.text_kv(self.txt, out=self.kv)
             self.gmap_img[:, 1].zero_()
             self.vp_img[:, 1].zero_()
+            self.cur_gmap_idx.fill_(2)
+
+    def set_current_node(self, cur_gmap_idx):
+        """Position of each episode's current node in the graph-map token order (int tensor / list [B], >= 2)."""
+        with torch.no_grad():
+            self.cur_gmap_idx.copy_(torch.as_tensor(cur_gmap_idx, device=self.cur_gmap_idx.device, dtype=torch.int64))
 
     def set_gmap_img(self, gmap_img_embeds):
-        """New graph-map node embeddings (any float dtype); slots 1 and 2 are owned by the runner."""
+        """New graph-map node embeddings (any float dtype); slot 1 ([MEM]) and the current node's slot (cur_gmap_idx,
+        rewritten by the next step) are owned by the runner."""
         with torch.no_grad():
             mem = self.vp_img[:, 1].clone()
             self.gmap_img.copy_(gmap_img_embeds)
             self.gmap_img[:, 1] = mem
 
-    def _body(self):
-        m = self.model
-        pe, pm, pf = m('panorama', self.pano)
-        nb = dict(self.nav)
+    def load_nav(self, nav_inputs):
+        """Copy a step's navigation inputs (e.g. BatchedGraphMap.nav_inputs(), G <= the static G) into the static buffers,
+        padding the graph-map side behind the masks: padded nodes are masked, unvisited, distance 0, no fusion source.
+        Graph-map slot 1 keeps the runner's [MEM]."""
+        G = self.gmap_img.shape[1]
+        with torch.no_grad():
+            g = nav_inputs['gmap_masks'].shape[1]
+            if g > G or nav_inputs['vp_masks'].shape[1] != self.vp_img.shape[1]:
+                raise DsrgHipError('GraphedNavStep.load_nav: %d graph nodes > static %d, or viewpoint length differs' % (g, G))
+            for k in self.NAV_KEYS:
+                src, dst = nav_inputs.get(k), self.nav.get(k)
+                if src is None or dst is None:
+                    if (src is None) != (dst is None):
+                        raise DsrgHipError('GraphedNavStep.load_nav: %s present on one side only' % k)
+                    continue
+                if k.startswith('gmap') and g < G:
+                    dst.fill_(-1 if k == 'gmap_src' else 0)
+                if k == 'gmap_pair_dists':
+                    dst[:, :g, :g] = src
+                elif k.startswith('gmap'):
+                    dst[:, :g] = src.to(dst.dtype)
+                else:
+                    dst.copy_(src)
+            mem = self.vp_img[:, 1].clone()
+            if g < G:
+                self.gmap_img.zero_()
+            self.gmap_img[:, :g] = nav_inputs['gmap_img_embeds'].to(self.gmap_img.dtype)
+            self.gmap_img[:, 1] = mem
+
+    def _pano_body(self):
+        pe, pm, pf = self.model('panorama', self.pano)
         self.vp_img[:, 2:] = pe
-        self.gmap_img[:, 2] = pf
+        self.pano_out = (pe, pm, pf)
+
+    def _nav_body(self):
+        nb = dict(self.nav)
         nb.update(vp_img_embeds=self.vp_img, gmap_img_embeds=self.gmap_img,
                   txt_embeds=self.txt, txt_masks=self.txt_masks, txt_kv=self.kv)
-        o = m('navigation', nb)
+        o = self.model('navigation', nb)
         self.vp_img[:, 1] = o['cls_embeds']
         self.gmap_img[:, 1] = o['cls_embeds']
+        pe, pm, pf = self.pano_out
         self.out = {'pano_embeds': pe, 'pano_fused': pf, **o}
 
-    def step(self):
-        if self.graph is not None:
-            self.graph.replay()
+    def _body(self):
+        self._pano_body()
+        self.gmap_img[self._rows, self.cur_gmap_idx] = self.pano_out[2]
+        self._nav_body()
+
+    def _run(self, graph, fn):
+        self._check_weights()
+        if graph is not None:
+            graph.replay()
         else:
             with torch.no_grad():
-                self._body()
+                fn()
+
+    def step(self):
+        """panorama + navigation in one replay; the pooled panorama goes to the current node's graph-map slot."""
+        if self.split:
+            raise DsrgHipError('GraphedNavStep(split=True): call pano_step() / nav_step()')
+        self._run(self.graph, self._body)
+        return self.out
+
+    def pano_step(self):
+        """split mode: the panorama call -> (pano_embeds, pano_masks, pano_fused), static tensors"""
+        if not self.split:
+            raise DsrgHipError('GraphedNavStep: pano_step() needs split=True')
+        self._run(self.graph_pano, self._pano_body)
+        return self.pano_out
+
+    def nav_step(self):
+        """split mode: the navigation call on the static buffers (fill them with load_nav() / set_gmap_img())"""
+        if not self.split:
+            raise DsrgHipError('GraphedNavStep: nav_step() needs split=True')
+        self._run(self.graph_nav, self._nav_body)
         return self.out

@@ -130,6 +130,9 @@ class GlocalTextPathNavCMT(nn.Module):
         self.config = cfg = config
         self.compute_dtype = compute_dtype
         h, eps = cfg.hidden_size, cfg.layer_norm_eps
+        if h != 64 * cfg.num_attention_heads or cfg.obj_v2_size % 64:
+            raise DsrgHipError('the attention kernels are built for head dim 64: hidden_size %d / %d heads, obj_v2_size %d'
+                               % (h, cfg.num_attention_heads, cfg.obj_v2_size))
         emb = nn.Module()
         emb.word_embeddings = nn.Embedding(cfg.vocab_size, h, padding_idx=0)
         emb.position_embeddings = nn.Embedding(cfg.max_position_embeddings, h)
@@ -219,8 +222,13 @@ class GlocalTextPathNavCMT(nn.Module):
             pre = cls.base_model_prefix + '.'
             sd = {(k[len(pre):] if k.startswith(pre) else k): v for k, v in state_dict.items()}
             own = model.state_dict()
-            sd = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
-            model.load_state_dict(sd, strict=False)
+            bad = ['%s: checkpoint %s vs model %s' % (k, tuple(v.shape), tuple(own[k].shape)) for k, v in sd.items()
+                   if k in own and tuple(v.shape) != tuple(own[k].shape)]
+            if bad:      # HF's from_pretrained(state_dict=) raises on a size mismatch too (vlnbert_init.py:110-113)
+                raise DsrgHipError('from_pretrained: size mismatch for ' + '; '.join(bad[:8]))
+            # unknown keys (mlm_head / image_classifier / lang_* sub-layers of a pre-training checkpoint) and missing ones
+            # (RMF / IGL, randomly initialised at fine-tune start) are tolerated, as in the reference
+            model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
         return model.eval()
 
     def invalidate_caches(self):
@@ -347,6 +355,7 @@ class GlocalTextPathNavCMT(nn.Module):
             if self._wgrad is not None and self._wgrad[0] == ver:
                 return self._wgrad[1]
         W = pk.resolve(dict(W0))
+        self._kv_cache = None        # the cached text K/V panel was projected with the previous pack
         if grad:
             self._wgrad = (ver, W)
         else:

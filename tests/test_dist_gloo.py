@@ -3,6 +3,10 @@
     and gathering code is the product's), the gathered result equals the unsharded one bit for bit;
   * DDP wrapper: gradients equal the mean over ranks, with and without the bf16 compression hook, with a parameter
     that is unused on one rank (find_unused_parameters semantics);
+  * the same on the PRODUCT pre-training model's parameter-pack path (functional._PackFn, one autograd node that every
+    parameter reaches): two ranks that touch different heads must still complete every DDP bucket
+    (MATERIALIZE_UNUSED_GRADS) and end with identical, rank-averaged gradients;
+  * `python bench.py --gpus 2` without a launcher starts two ranks itself (launch plumbing, gloo, no GPU);
   * task-id broadcast and max-over-ranks timing reduction used by bench.py."""
 import os
 import socket
@@ -109,3 +113,71 @@ def test_shard_slice_covers_everything():
             s = [shard_slice(n, r, w) for r in range(w)]
             assert s[0][0] == 0 and s[-1][1] == n and all(s[i][1] == s[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in s) - min(b - a for a, b in s) <= 1
+
+
+def _ddp_pack_case(rank, world, D):
+    """GlocalTextPathCMTPreTraining (small config, CPU-constructible: the module tree only HOLDS parameters) under DDP.
+    The forward below is the product's own weight-pack path (bert._weights() + _hw(): _PackFn over all ~300 parameters)
+    followed by a torch reduction over a rank-dependent subset of the packed weights, standing in for the HIP kernels
+    that consume them; what is under test is that DDP's reducer sees a gradient for every parameter."""
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain import GlocalTextPathCMTPreTraining
+    torch.manual_seed(0)
+    cfg = DSRGConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, vocab_size=512, num_l_layers=1, num_x_layers=1,
+                     num_pano_layers=1, image_feat_size=128, use_lang2visn_attn=True, obj_feat_size=0, image_prob_size=16,
+                     pretrain_tasks=('mlm', 'mrc', 'sap'))
+    model = GlocalTextPathCMTPreTraining(cfg, compute_dtype=torch.bfloat16)    # bf16: every weight goes through the pack
+
+    class Step(torch.nn.Module):
+        def __init__(s, m):
+            super().__init__(); s.m = m
+
+        def forward(s, task):
+            W, Hd = s.m.bert._weights(), s.m._hw()
+            if task == 'sap':        # touches x-layer + SAP-head weights, not the MLM head / lang2visn sub-layers
+                ts = [W['x.g.0.qkv.w'], W['x.l.0.ff1.w'], Hd['global_sap_head.l1.w'], Hd['sap_fuse_linear.w2']]
+            else:                    # touches the text-side sub-layers + MLM head (tied decoder), not the SAP heads
+                ts = [W['x.g.0.lqkv.w'], W['lang.0.qkv.w'], Hd['mlm.t.w'], Hd['mlm.dec.w']]
+            return sum((t.float() * (1.0 + 0.5 * i)).sum() for i, t in enumerate(ts))
+    ddp = D.wrap_model(Step(model), bucket_cap_mb=1)
+    out = []
+    for it in range(2):                                   # a second iteration fails if a bucket of the first never finished
+        model.zero_grad(set_to_none=True)
+        ddp('sap' if (rank + it) % 2 == 0 else 'mlm').backward()
+        named = dict(model.named_parameters())
+        out.append({k: named[k].grad.clone().numpy() for k in (
+            'bert.global_encoder.encoder.x_layers.0.visn_self_att.self.query.weight', 'global_sap_head.net.0.weight',
+            'mlm_head.predictions.transform.dense.weight', 'bert.embeddings.word_embeddings.weight',
+            'bert.global_encoder.encoder.x_layers.0.lang_self_att.self.key.weight', 'image_classifier.net.0.weight')})
+    return out
+
+
+def test_ddp_on_product_pack_path_completes_buckets():
+    r = _run(_ddp_pack_case)
+    for it in range(2):
+        g0, g1 = r[0][it], r[1][it]
+        for k in g0:
+            assert np.array_equal(g0[k], g1[k]), k
+        # each tensor is touched on exactly one rank with coefficient c -> rank-mean gradient c / 2; untouched -> 0
+        assert np.allclose(g0['bert.global_encoder.encoder.x_layers.0.visn_self_att.self.query.weight'], 0.5)
+        assert np.allclose(g0['global_sap_head.net.0.weight'], 1.0)
+        assert np.allclose(g0['bert.global_encoder.encoder.x_layers.0.lang_self_att.self.key.weight'], 0.5)
+        assert np.allclose(g0['mlm_head.predictions.transform.dense.weight'], 1.0)
+        assert np.allclose(g0['bert.embeddings.word_embeddings.weight'], 1.25)      # tied MLM decoder
+        assert np.allclose(g0['image_classifier.net.0.weight'], 0.0)                 # no rank touched it
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """bench.py --gpus 2 with no launcher: the parent starts 2 ranks before anything touches a GPU (selftest mode stops
+    after the rendezvous, so this runs without a device); a launcher whose WORLD_SIZE disagrees with --gpus is an error."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['DSRG_BENCH_SPAWN_SELFTEST'] = '1'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, RANK='0', WORLD_SIZE='3'),
+                       capture_output=True, timeout=300)
+    assert p.returncode != 0 and b'WORLD_SIZE=3' in p.stderr

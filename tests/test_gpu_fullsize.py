@@ -23,9 +23,9 @@ def _model(dtype, sd=None):
     return GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict=sd, compute_dtype=dtype).cuda().eval()
 
 
-def _step_inputs(B, L, G, seed, dev='cuda'):
+def _step_inputs(B, L, G, seed, dev='cuda', O=3):
     lb = common.to_t(synth.language_batch(B, L, seed), dev)
-    pbn = synth.panorama_batch(B, 36, 3, seed)
+    pbn = synth.panorama_batch(B, 36, O, seed)
     nb = common.to_t(synth.navigation_batch(B, G, 38, seed, ncand=pbn['ncand'], nav_types=pbn['nav_types']), dev)
     return lb, common.to_t(pbn, dev), nb
 
@@ -57,10 +57,12 @@ def _same(a, b, tol):
     return float((a[fa].float() - b[fb].float()).abs().max()) <= tol
 
 
-@pytest.mark.parametrize('L,G,B,reverie', [(80, 20, 64, False), (250, 100, 32, False), (80, 20, 64, True)])
-def test_full_size_chain_matches_oracle(L, G, B, reverie):
+@pytest.mark.parametrize('L,G,B,reverie,O', [(80, 20, 64, False, 3), (250, 100, 32, False, 3), (80, 20, 64, True, 3),
+                                             (80, 20, 16, False, 20), (80, 20, 16, True, 20)])
+def test_full_size_chain_matches_oracle(L, G, B, reverie, O):
     """configs[1] and configs[2] (REVERIE, 20 object tokens, OG head) at full batch and the configs[4] shapes: recurrent
-    chain, HIP fp32 vs the CPU oracle."""
+    chain, HIP fp32 vs the CPU oracle.  O=20 is configs[2]'s stated upper end ("<= 20 objects/view": 720 object tokens per
+    episode through the ASV encoder, vilmodel.py:697-714, vilmodel_reverie.py:689-759) at model level, R2R and REVERIE."""
     from dsrg_amd.config import DSRGConfig
     from oracle import dsrg_oracle
     tag = 'reverie_c3' if reverie else 'r2r_c1'
@@ -70,21 +72,23 @@ def test_full_size_chain_matches_oracle(L, G, B, reverie):
         m = GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict=sd, compute_dtype=torch.float32).cuda().eval()
     else:
         m = _model(torch.float32, sd)
-    meta = [B, L, G, 3, 42, int(reverie), 20 if reverie else 0]
-    steps = 3 if L == 80 else 2
+    meta = [B, L, G, O, 42, int(reverie), 20 if reverie else 0]
+    steps = 3 if (L == 80 and O == 3) else 2
     with torch.no_grad():
         out = common.run_chain(lambda mode, b: m(mode, b), meta, device='cuda', steps=steps)
         ref = common.run_chain(lambda mode, b: dsrg_oracle.forward(sd, DSRGConfig(), mode, b, reverie=reverie), meta, device='cpu', steps=steps)
     errs = common.compare(out, ref, tol=1e-3, logit_tol=1e-3, steps=steps)
-    print('B=%d L=%d G=%d reverie=%s fp32 vs oracle' % (B, L, G, reverie), {k: '%.1e' % v for k, v in errs.items() if 'logits' in k})
+    print('B=%d L=%d G=%d O=%d reverie=%s fp32 vs oracle' % (B, L, G, O, reverie), {k: '%.1e' % v for k, v in errs.items() if 'logits' in k})
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_episodes_are_independent_at_full_batch(dtype):
+@pytest.mark.parametrize('dtype,L,G,O', [(torch.float32, 80, 20, 3), (torch.bfloat16, 80, 20, 3), (torch.float32, 250, 100, 3),
+                                         (torch.bfloat16, 250, 100, 3), (torch.bfloat16, 80, 20, 20)])
+def test_episodes_are_independent_at_full_batch(dtype, L, G, O):
     """Rows of a 64-episode step == the same episodes run as a batch of 8 (different tile shapes and grids, same
-    per-element arithmetic order): no cross-episode term anywhere on the path."""
+    per-element arithmetic order): no cross-episode term anywhere on the path.  Also at configs[4]'s per-GPU share
+    (64 episodes, 250 instruction tokens, 100 graph nodes) and at 20 objects per view in the product dtype."""
     m = _model(dtype)
-    lb, pb, nb = _step_inputs(64, 80, 20, 777)
+    lb, pb, nb = _step_inputs(64, L, G, 777, O=O)
     full = _one_step(m, lb, pb, nb)
     part = _one_step(m, _slice(lb, 8), _slice(pb, 8), _slice(nb, 8))
     tol = 1e-5 if dtype == torch.float32 else 1e-2
@@ -124,13 +128,13 @@ def test_padding_behind_masks_changes_nothing():
     assert (pad['fused_logits'].argmax(1) == base['fused_logits'].argmax(1)).all()
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_graph_replay_equals_eager_at_full_batch(dtype):
+@pytest.mark.parametrize('dtype,L,G', [(torch.float32, 80, 20), (torch.bfloat16, 80, 20), (torch.bfloat16, 250, 100)])
+def test_graph_replay_equals_eager_at_full_batch(dtype, L, G):
     """GraphedNavStep (HIP graph, forked streams, static buffers, hoisted text K/V) == eager launches, bit for bit,
-    over 3 recurrent steps at B=64."""
+    over 3 recurrent steps at B=64 (R2R shapes and the configs[4] shapes)."""
     from dsrg_amd.runner import GraphedNavStep
     m = _model(dtype)
-    lb, pb, nb = _step_inputs(64, 80, 20, 313)
+    lb, pb, nb = _step_inputs(64, L, G, 313)
     with torch.no_grad():
         txt = m('language', lb)
     runs = []
@@ -204,3 +208,114 @@ def test_minimal_and_ragged_shapes_match_oracle(B, L, G, reverie):
         out = common.run_chain(lambda mode, b: m(mode, b), meta, device='cuda', steps=2)
         ref = common.run_chain(lambda mode, b: dsrg_oracle.forward(sd, DSRGConfig(), mode, b, reverie=reverie), meta, device='cpu', steps=2)
     common.compare(out, ref, tol=1e-3, logit_tol=1e-3, steps=2)
+
+
+def test_runner_current_node_slot_and_recapture_after_eval():
+    """(1) The pooled panorama goes to the CURRENT node's graph-map slot (cur_gmap_idx), not to slot 2 (the start viewpoint
+    after the first step: agent.py:165-187, 443-447); checked against direct model calls glued by hand.  (2) The captured
+    graph bakes in addresses of the model's packed weights: model.eval() (which the reference agent calls before every
+    test()) drops that pack; the runner must notice and re-capture instead of replaying freed memory."""
+    from dsrg_amd.runner import GraphedNavStep
+    m = _model(torch.bfloat16)
+    B = 16
+    lb, pb, nb = _step_inputs(B, 80, 20, 99)
+    with torch.no_grad():
+        txt = m('language', lb)
+    cur = (torch.arange(B, device='cuda') % 5) + 2
+
+    def by_hand():
+        with torch.no_grad():
+            pe, pm, pf = m('panorama', pb)
+            n = dict(nb)
+            z = torch.zeros(B, 1, 768, device='cuda', dtype=pe.dtype)
+            n['vp_img_embeds'] = torch.cat([z, z, pe], 1)
+            g = nb['gmap_img_embeds'].to(pe.dtype).clone()
+            g[:, 1] = 0
+            g[torch.arange(B, device='cuda'), cur] = pf
+            n.update(gmap_img_embeds=g, txt_embeds=txt, txt_masks=lb['txt_masks'])
+            return m('navigation', n)
+    want = by_hand()
+    r = GraphedNavStep(m, txt, lb['txt_masks'], pb, nb)
+    r.set_text(txt, lb['txt_masks'])
+    r.set_current_node(cur)
+    got = {k: v.clone() for k, v in r.step().items() if isinstance(v, torch.Tensor)}
+    for k in ('fused_logits', 'global_logits', 'cls_embeds'):
+        assert torch.equal(torch.nan_to_num(got[k].float(), neginf=-1e30), torch.nan_to_num(want[k].float(), neginf=-1e30)), k
+    g_old = r.graph
+    m.eval()                                                   # invalidate_caches(): the pack the graph points into is dropped
+    junk = [torch.full((1 << 22,), float('nan'), device='cuda') for _ in range(48)]      # reuse the freed blocks
+    r.set_text(txt, lb['txt_masks'])
+    r.set_current_node(cur)
+    again = r.step()
+    torch.cuda.synchronize()
+    assert r.graph is not g_old                                # re-captured
+    for k in ('fused_logits', 'global_logits', 'cls_embeds'):
+        assert torch.equal(torch.nan_to_num(again[k].float(), neginf=-1e30), torch.nan_to_num(want[k].float(), neginf=-1e30)), k
+    del junk
+
+
+def test_split_runner_with_device_graphmap_matches_oracle_rollout():
+    """GraphedNavStep(split=True) + BatchedGraphMap over a 4-step rollout against the CPU oracle model fed by the restated
+    reference GraphMap + builders (oracle/agent_oracle.py) on the same synthetic walks: the static graph-map buffers are
+    padded to 24 nodes behind the masks.  fp32; fused logits within 1e-3, same greedy actions, on every step."""
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.graphmap import BatchedGraphMap
+    from dsrg_amd.runner import GraphedNavStep
+    from oracle import dsrg_oracle, agent_oracle as AO
+    torch.set_num_threads(16)
+    B, T, V, L, seed, GS = 4, 4, 36, 40, 21, 24
+    cfg = DSRGConfig()
+    sd = common.synth_sd('r2r_c1')
+    m = _model(torch.float32, dict(sd))
+    obs, ended = synth.episode_walks(B, T, seed)
+    lb = synth.language_batch(B, L, seed)
+    t_cpu = dsrg_oracle.forward(sd, cfg, 'language', common.to_t(lb))
+    lbg = common.to_t(lb, 'cuda')
+    with torch.no_grad():
+        t_gpu = m('language', lbg)
+    gmaps = [AO.GraphMap(ob['viewpoint']) for ob in obs[0]]
+    for i, ob in enumerate(obs[0]):
+        gmaps[i].update_graph(ob)
+    gm = BatchedGraphMap(B, 768, 'cuda', dtype=torch.float32, max_nodes=48, max_cand=8)
+    gm.reset(obs[0])
+    pb0 = synth.panorama_batch(B, V, 3, seed)
+    nb0 = common.to_t(synth.navigation_batch(B, GS, V + 2, seed, ncand=pb0['ncand'], nav_types=pb0['nav_types']), 'cuda')
+    r = GraphedNavStep(m, t_gpu, lbg['txt_masks'], common.to_t(pb0, 'cuda'), nb0, split=True)
+    r.set_text(t_gpu, lbg['txt_masks'])
+    mem_c = None
+    for t in range(T):
+        cand = [[c['viewpointId'] for c in ob['candidate']] for ob in obs[t]]
+        pb = synth.panorama_batch(B, V, 3, seed + t)
+        pb['nav_types'] = np.stack([np.asarray([1] * len(c) + [0] * (V - len(c)), np.int64) for c in cand])
+        AO.step_begin(gmaps, obs[t], t, ended[t])
+        pe, pm, pf = dsrg_oracle.forward(sd, cfg, 'panorama', common.to_t(pb))
+        AO.update_embeds(gmaps, obs[t], cand, pe.numpy(), pf.numpy(), ended[t])
+        nav = AO.nav_gmap_variable(obs[t], gmaps, None if mem_c is None else mem_c.numpy())
+        nav.update(AO.nav_vp_variable(obs[t], gmaps, pe.numpy(), cand, [V] * B, pb['nav_types'], None if mem_c is None else mem_c.numpy()))
+        nbc = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in nav.items()}
+        nbc.update(txt_embeds=t_cpu, txt_masks=torch.from_numpy(lb['txt_masks']), vp_obj_masks=None)
+        o_c = dsrg_oracle.forward(sd, cfg, 'navigation', nbc)
+        mem_c = o_c['cls_embeds']
+        # ---- HIP side: pano graph -> device graph map -> nav graph
+        for k, v in common.to_t(pb, 'cuda').items():
+            if isinstance(v, torch.Tensor) and k in r.pano:
+                r.pano[k].copy_(v)
+        gm.begin_step(obs[t], t, ended[t])
+        pe_g, pm_g, pf_g = r.pano_step()
+        gm.update_embeds(pe_g, pf_g, ended[t])
+        ng = gm.nav_inputs(pe_g, r.pano['nav_types'], torch.full((B,), V, device='cuda'), None if t == 0 else r.out['cls_embeds'])
+        r.load_nav(ng)
+        o_g = r.nav_step()
+        G = ng['gmap_masks'].shape[1]
+        fc, fg = o_c['fused_logits'].numpy(), o_g['fused_logits'].float().cpu().numpy()
+        assert np.isneginf(fg[:, G:]).all()
+        fg = fg[:, :G]
+        fin = np.isfinite(fc)
+        assert (np.isfinite(fg) == fin).all() and np.abs(fg[fin] - fc[fin]).max() <= 1e-3, (t, np.abs(fg[fin] - fc[fin]).max())
+        assert np.array_equal(fg.argmax(1), fc.argmax(1))
+        assert int(gm.current_token_index(ng)[0]) >= 2
+        if t + 1 < T:
+            for i, ob in enumerate(obs[t + 1]):
+                if not ended[t + 1][i]:
+                    gmaps[i].update_graph(ob)
+            gm.observe(obs[t + 1], ended[t + 1])
