@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HeadTailProblem(C.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
     'dsrg_attention_fwd_grouped': (C.c_int, [C.POINTER(AttnProblem), _I, _I, _P, _P, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_attention_bwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
+    'dsrg_attention_bwd_noalloc': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
+                                             _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     'dsrg_layernorm_fwd_grouped': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _P]),
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,

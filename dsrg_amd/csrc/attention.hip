@@ -694,13 +694,13 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
   return dsrg_attention_fwd_grouped(&p, 1, mask_mode, sprel_w, sprel_b, B, NH, scale, p_drop, seed, dtype, stream);
 }
 
-extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
-                                  const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
-                                  const void* dO, int64_t do_bs, int do_rs, const float* lse,
-                                  const uint8_t* kmask, int mask_mode, const float* pair_dists,
-                                  const float* sprel_w, const float* sprel_b,
-                                  void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
-                                  int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                              const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                              const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                              const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                              const float* sprel_w, const float* sprel_b,
+                              void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
+                              int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
   DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_attention_bwd: p_drop=%g out of [0,1)", (double)p_drop);
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_bwd: bad dtype %d", dtype);
   DSRG_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws, "dsrg_attention_bwd: null pointer");
@@ -727,4 +727,62 @@ extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const v
   }
   DSRG_LAUNCH_CHECK("dsrg_attention_bwd");
   return DSRG_OK;
+}
+
+extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                                  const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                                  const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                                  const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                                  const float* sprel_w, const float* sprel_b,
+                                  void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
+                                  int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+  return attention_bwd_impl(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, dO, do_bs, do_rs, lse, kmask, mask_mode, pair_dists,
+                            sprel_w, sprel_b, dQ, dK, dV, delta_ws, dsprel, B, NH, Nq, Nk, scale, p_drop, seed, dtype, stream);
+}
+
+// ---- the allocation-free variant (include/dsrg_hip.h: dsrg_attention_bwd_noalloc).  The delta workspace
+// (delta_i = dO_i . O_i per (episode, head, query row), written by the dQ kernel, read by the dK/dV kernel) lives in a
+// file-scope device array instead of caller memory.  The array's name is a HOST-side handle: the device address is
+// taken once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) float scratch[DSRG_ATTN_BWD_NOALLOC_MAX_ROWS];     // 4 MiB on every GPU the library runs on
+
+static int scratch_ptr(float** out) {
+  static std::mutex mu;
+  static float* ptr[DSRG_MAX_DEVICES] = {};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DSRG_MAX_DEVICES) {
+    dsrg_set_error("dsrg_attention_bwd_noalloc: no current device, or device index %d >= %d", dev, DSRG_MAX_DEVICES);
+    return DSRG_EINVAL;
+  }
+  std::lock_guard<std::mutex> g(mu);
+  if (!ptr[dev]) {
+    float* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));     // this device's copy
+    if (e != hipSuccess || !p) {
+      dsrg_set_error("dsrg_attention_bwd_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return DSRG_ELAUNCH;
+    }
+    ptr[dev] = p;
+  }
+  *out = ptr[dev];
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_attention_bwd_noalloc(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                                          const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                                          const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                                          const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                                          const float* sprel_w, const float* sprel_b,
+                                          void* dQ, void* dK, void* dV, float* dsprel,
+                                          int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+  DSRG_CHECK(B >= 0 && NH >= 1 && Nq >= 0, "dsrg_attention_bwd_noalloc: bad dims");
+  DSRG_CHECK((int64_t)B * NH * Nq <= (int64_t)DSRG_ATTN_BWD_NOALLOC_MAX_ROWS,
+             "dsrg_attention_bwd_noalloc: B*NH*Nq = %lld exceeds the static workspace of %d rows; use dsrg_attention_bwd with a caller workspace",
+             (long long)B * NH * Nq, DSRG_ATTN_BWD_NOALLOC_MAX_ROWS);
+  float* ws = nullptr;
+  const int rc = scratch_ptr(&ws);
+  if (rc != DSRG_OK) return rc;
+  // nothing to clear: rows [0, B*NH*Nq) are all written by the dQ kernel before the dK/dV kernel (same stream) reads them
+  return attention_bwd_impl(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, dO, do_bs, do_rs, lse, kmask, mask_mode, pair_dists,
+                            sprel_w, sprel_b, dQ, dK, dV, ws, dsprel, B, NH, Nq, Nk, scale, p_drop, seed, dtype, stream);
 }

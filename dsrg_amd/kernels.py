@@ -217,6 +217,28 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     return dq, dk, dv, dsp
 
 
+def attention_bwd_noalloc(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, dq, dk, dv, dsp=None, scale=0.125,
+                          p_drop=0.0, seed=0):
+    """dsrg_attention_bwd_noalloc: the caller passes every output (dq, dk, dv contiguous, dsp zeroed fp32 [2] or None); the
+    delta workspace is the library's static device array.  Nothing is allocated here or in the library."""
+    lib = _lib.load()
+    B, Nq, _ = q.shape
+    Nk = k.shape[1]
+    _check_heads(nh, q, k, v, o, do, dq, dk, dv)
+    for t in (dq, dk, dv):
+        if not t.is_contiguous() or t.dtype != q.dtype:
+            raise _lib.DsrgHipError('attention_bwd_noalloc: dq / dk / dv must be contiguous and of the input dtype')
+    if do.stride(2) != 1:
+        raise _lib.DsrgHipError('attention_bwd_noalloc: dO rows must be contiguous (no copy is made here)')
+    bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
+    _lib.check(lib.dsrg_attention_bwd_noalloc(
+        _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
+        _p(do), bs(do), do.stride(1), _p(lse), _p(kmask), mask_mode if kmask is not None else _lib.MASK_NONE, _p(dists),
+        _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(dsp), B, nh, Nq, Nk, float(scale), float(p_drop), int(seed),
+        _dt(q), _stream()), 'dsrg_attention_bwd_noalloc')
+    return dq, dk, dv, dsp
+
+
 def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
     lib = _lib.load()
     _dev(x)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 7
+#define DSRG_ABI_VERSION 8
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -283,6 +283,23 @@ int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int
                        const float* sprel_w, const float* sprel_b,
                        void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
                        int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+
+/* dsrg_attention_bwd without the workspace argument, for callers that cannot allocate: code under HIP-graph capture,
+ * tight serving / fine-tuning loops, harnesses that forbid hipMalloc.  NO counterpart in the reference (its autograd
+ * allocates freely); everything else is dsrg_attention_bwd (same kernels, same results bit for bit).  The delta
+ * workspace is a static device array of DSRG_ATTN_BWD_NOALLOC_MAX_ROWS floats (4 MiB, held on every GPU the library
+ * runs on until the process ends): B*NH*Nq above that is rejected with DSRG_EINVAL.  The entry point calls no
+ * hipMalloc / hipFree / allocating routine.  Every call on a GPU shares that GPU's array: two calls that overlap on one
+ * GPU (different streams, or different threads) RACE - serialise them on one stream.  Nothing needs clearing between
+ * calls (each call writes every row it later reads). */
+#define DSRG_ATTN_BWD_NOALLOC_MAX_ROWS (1 << 20)
+int dsrg_attention_bwd_noalloc(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                               const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                               const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                               const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                               const float* sprel_w, const float* sprel_b,
+                               void* dQ, void* dK, void* dV, float* dsprel,
+                               int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* Backward of the row kernels (each recomputes its forward values; parameter gradients are accumulated with float
  * atomics into fp32 buffers the caller has zeroed; activation gradients are written in the storage dtype). */
