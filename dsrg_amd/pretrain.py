@@ -35,11 +35,12 @@ class GlocalTextPathCMT(_Backbone):
 
     def _trajectory(self, b):
         """ImageEmbeddings.forward over all steps of all trajectories at once (vilmodel.py:497-546): identical
-        arithmetic to the fine-tune panorama mode, so it IS that code path."""
+        arithmetic to the fine-tune panorama mode, so it IS that code path.  Also returns the per-step token counts
+        (views, or views + objv1 objects for REVERIE) that the viewpoint encoder masks with."""
         pano, masks, fused = self.forward_panorama_per_step(
             b['traj_view_img_fts'], b['traj_objv2_fts'], b['traj_loc_fts'], b['traj_nav_types'],
             b['traj_vp_view_lens'], b['traj_objv2_lens'])
-        return pano, fused
+        return pano, fused, b['traj_vp_view_lens']
 
     @staticmethod
     def gmap_aggregation_indices(traj_step_lens, traj_vpids, traj_cand_vpids, gmap_vpids, V, G):
@@ -78,7 +79,7 @@ class GlocalTextPathCMT(_Backbone):
         gmask = (torch.arange(G, device=dev)[None] < b['gmap_lens'][:, None]).contiguous()
         return g, gmask
 
-    def _vp_input(self, W, pano, b):
+    def _vp_input(self, W, pano, b, tok_lens):
         cfg, cd = self.config, self.compute_dtype
         S, V, H = pano.shape
         dev = pano.device
@@ -86,7 +87,7 @@ class GlocalTextPathCMT(_Backbone):
         last = torch.from_numpy(last_np).to(dev)
         B = last.shape[0]
         T = b['vp_pos_fts'].shape[1]                 # = max(last view_len) + 1  ([stop] first)
-        vp_lens = b['traj_vp_view_lens'].index_select(0, last) + 1
+        vp_lens = tok_lens.index_select(0, last) + 1
         # token (i, 0) = zeros ([stop]), token (i, t >= 1) = view t-1 of trajectory i's last step: the same gather kernel
         tt = np.arange(1, T)
         dst = (np.arange(B)[:, None] * T + tt[None]).reshape(-1)
@@ -101,9 +102,9 @@ class GlocalTextPathCMT(_Backbone):
     def forward_backbone(self, b, return_gmap_embeds=True):
         W = self._weights()
         txt, tm = self._text(b['txt_ids'], b['txt_lens'])
-        pano, fused = self._trajectory(b)
+        pano, fused, tok_lens = self._trajectory(b)
         kv = self.text_kv(txt) if not torch.is_grad_enabled() else Fn.linear(txt, W['x.txtkv.w'], W['x.txtkv.b'])
-        v, vmask, last = self._vp_input(W, pano, b)
+        v, vmask, last = self._vp_input(W, pano, b, tok_lens)
         tm = tm.contiguous()
         if return_gmap_embeds:
             g, gmask = self._gmap_input(W, pano, fused, b)
@@ -120,9 +121,9 @@ class GlocalTextPathCMT(_Backbone):
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         txt, tm = self._text(b['txt_ids'], b['txt_lens'])
         tm = tm.contiguous()
-        pano, fused = self._trajectory(b)
+        pano, fused, tok_lens = self._trajectory(b)
         g, gmask = self._gmap_input(W, pano, fused, b)
-        v, vmask, _ = self._vp_input(W, pano, b)
+        v, vmask, _ = self._vp_input(W, pano, b, tok_lens)
         ctx, cmask, brs = [g, v], [gmask, vmask], ('g', 'l')
         t = [txt, txt]
         for i in range(nl):
@@ -151,11 +152,13 @@ def _region_head(h, n_out):   # RegionClassification, pretrain_cmt.py:12-23
 
 
 class GlocalTextPathCMTPreTraining(nn.Module):
+    BACKBONE = GlocalTextPathCMT
+
     def __init__(self, config, compute_dtype=torch.bfloat16):
         super().__init__()
         self.config = cfg = config
         h = cfg.hidden_size
-        self.bert = GlocalTextPathCMT(cfg, compute_dtype=compute_dtype)
+        self.bert = self.BACKBONE(cfg, compute_dtype=compute_dtype)
         tasks = list(getattr(cfg, 'pretrain_tasks', ()))
         if 'mlm' in tasks:
             pred = _mod(transform=_dense_ln(h, h, cfg.layer_norm_eps), decoder=nn.Linear(h, cfg.vocab_size, bias=False))
@@ -239,6 +242,10 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             return self.forward_mrc(b, compute_loss)
         elif task.startswith('sap'):
             return self.forward_sap(b, compute_loss)
+        elif task.startswith('og'):
+            return self.forward_og(b, compute_loss)
+        elif task.startswith('valid_sap_og'):
+            return self.forward_sap_og(b)
         raise ValueError('invalid task')
 
     def forward_mlm(self, b, compute_loss=True):   # pretrain_cmt.py:142-167
@@ -253,28 +260,86 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             return F.cross_entropy(scores, b['txt_labels'][sel], reduction='none')
         return scores
 
-    def forward_mrc(self, b, compute_loss=True):   # pretrain_cmt.py:175-228 (R2R: view regions only)
-        W, cd = self._hw(), self.bert.compute_dtype
+    def _region_logits(self, W, key, x):
+        """RegionClassification (pretrain_cmt.py:12-23): Linear+ReLU in the GEMM epilogue -> LayerNorm -> Linear(H, n_classes)"""
+        cd = self.bert.compute_dtype
+        h = Fn.linear(x, W[key + '.l1.w'], W[key + '.l1.b'], act=ACT_RELU, out_f32=True)
+        h = Fn.layernorm(h, W[key + '.ln.g'], W[key + '.ln.b'], 1e-12, out_dtype=cd)
+        return Fn.linear(h, W[key + '.l2.w'], W[key + '.l2.b'], out_f32=True)
+
+    @staticmethod
+    def _token_slices(v, start, lens, T):
+        """[B, T, H]: row i = v[i, start_i : start_i + lens_i] zero-padded (the reference's pad_tensors_wgrad over per-sample
+        slices, pretrain_cmt.py:191-194, 203-206, 313-317; slices are clipped at the end of v like Python slicing)."""
+        B, N, H = v.shape
+        pos = torch.arange(T, device=v.device)[None]
+        idx = start[:, None] + pos
+        ok = (pos < lens[:, None]) & (idx < N)
+        rows = torch.gather(v, 1, idx.clamp(max=N - 1)[..., None].expand(B, T, H))
+        return rows * ok[..., None].to(v.dtype), ok
+
+    def _last_lens(self, b, last):
+        vl = b['traj_vp_view_lens'].index_select(0, last)
+        ol = b['traj_vp_obj_lens'].index_select(0, last) if b.get('traj_vp_obj_lens') is not None else torch.zeros_like(vl)
+        return vl, ol
+
+    def forward_mrc(self, b, compute_loss=True):   # pretrain_cmt.py:175-228
+        W = self._hw()
         _, v, last = self.bert.forward_backbone(b, return_gmap_embeds=False)
+        vl, ol = self._last_lens(b, last)
         m = b['vp_view_mrc_masks']
-        T = m.shape[1]
-        lens = b['traj_vp_view_lens'].index_select(0, last)
-        ve = v[:, 1:1 + T]
-        if ve.shape[1] < T:
-            ve = F.pad(ve, (0, 0, 0, T - ve.shape[1]))
-        ve = ve * (torch.arange(T, device=v.device)[None] < lens[:, None])[..., None].to(ve.dtype)
-        x = ve[m].contiguous()
-        h = Fn.linear(x, W['image_classifier.l1.w'], W['image_classifier.l1.b'], act=ACT_RELU, out_f32=True)
-        h = Fn.layernorm(h, W['image_classifier.ln.g'], W['image_classifier.ln.b'], 1e-12, out_dtype=cd)
-        logits = Fn.linear(h, W['image_classifier.l2.w'], W['image_classifier.l2.b'], out_f32=True)
+        ve, _ = self._token_slices(v, torch.ones_like(vl), vl, m.shape[1])          # [stop] at 0
+        logits = self._region_logits(W, 'image_classifier', ve[m].contiguous())
         tgt = b['vp_view_probs'][m]
+        ologits = otgt = None
+        if b.get('traj_obj_img_fts') is not None:                                    # object regions (REVERIE), :202-213
+            om = b['vp_obj_mrc_masks']
+            oe, _ = self._token_slices(v, vl + 1, ol, om.shape[1])
+            key = 'obj_classifier' if getattr(self, 'obj_classifier', None) is not None else 'image_classifier'
+            ologits = self._region_logits(W, key, oe[om].contiguous())
+            otgt = b['vp_obj_probs'][om]
         if not compute_loss:
-            return logits, tgt, None, None
-        return F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+            return logits, tgt, ologits, otgt
+        loss = F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+        if ologits is not None:
+            loss = torch.cat([loss, F.kl_div(F.log_softmax(ologits, -1), otgt, reduction='none').sum(1)], 0)
+        return loss
+
+    def _og_logits(self, W, b, v, last):   # pretrain_cmt.py:313-321
+        vl, ol = self._last_lens(b, last)
+        T = int(ol.max())
+        oe, _ = self._token_slices(v, vl + 1, ol, T)
+        sc = self._scores(W, 'og_head', oe.contiguous())
+        return sc.masked_fill(torch.arange(T, device=v.device)[None] >= ol[:, None], -float('inf'))
+
+    def forward_og(self, b, compute_loss=True):   # pretrain_cmt.py:296-327
+        W = self._hw()
+        _, v, last = self.bert.forward_backbone(b, return_gmap_embeds=False)
+        obj_logits = self._og_logits(W, b, v, last)
+        if compute_loss:
+            return F.cross_entropy(obj_logits, b['obj_labels'], reduction='none')
+        return obj_logits
+
+    def forward_sap_og(self, b):   # pretrain_cmt.py:329-392
+        """NB the reference's own call here drops the objv2 features (`self.bert(...)` without traj_objv2_fts, :337-341), which
+        its objv2 backbones cannot run without (AttributeError at vilmodel.py:502 / vilmodel_reverie.py:526), and no driver
+        ever uses the task; this is the evident intent: SAP logits and OG logits from ONE backbone pass."""
+        W = self._hw()
+        g, v, last = self.bert.forward_backbone(b)
+        gl, ll, fl = self._sap_logits(W, b, g, v, last)
+        return gl, ll, fl, self._og_logits(W, b, v, last)
 
     def forward_sap(self, b, compute_loss=True):   # pretrain_cmt.py:230-294
         W = self._hw()
         g, v, last = self.bert.forward_backbone(b)
+        gl, ll, fl = self._sap_logits(W, b, g, v, last)
+        if not compute_loss:
+            return gl, ll, fl, b['global_act_labels'], b['local_act_labels']
+        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
+            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
+            + F.cross_entropy(fl, b['global_act_labels'], reduction='none')
+
+    def _sap_logits(self, W, b, g, v, last):   # pretrain_cmt.py:248-285
         B, G, _ = g.shape
         T = v.shape[1]
         dev = g.device
@@ -285,10 +350,5 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         nav_ok = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), nav_last[:, :T - 1] == 1], 1).contiguous()
         cands = [[None] + list(c[-1]) for c in b['traj_cand_vpids']]
         src, bw = self.bert.fusion_indices(b['gmap_vpids'], b['gmap_visited_masks'], cands, G, T, skip=1)
-        gl, ll, fl = Fn.nav_logits(sg, sl, fr, gmask, b['gmap_visited_masks'].contiguous(), nav_ok,
-                                   torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev))
-        if not compute_loss:
-            return gl, ll, fl, b['global_act_labels'], b['local_act_labels']
-        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
-            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
-            + F.cross_entropy(fl, b['global_act_labels'], reduction='none')
+        return Fn.nav_logits(sg, sl, fr, gmask, b['gmap_visited_masks'].contiguous(), nav_ok,
+                             torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev))

@@ -200,7 +200,7 @@ def navigation_batch(B, G=20, Vp=38, seed=0, ncand=None, nav_types=None, vp_lens
 # --------------------------------------------------------------------------
 # pre-training trajectory batches (pretrain_src/data/tasks.py collators, dataset.py get_input)
 # --------------------------------------------------------------------------
-def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V=36, n_classes=1000):
+def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V=36, n_classes=1000, reverie=False, No=20):
     """One collated batch for GlocalTextPathCMTPreTraining.forward(batch, task).
     Trajectories of T_i steps; graph-map tokens [stop], visited (= trajectory viewpoints), unvisited (every
     candidate ever seen that was never visited; some are seen from two steps, so the aggregation averages)."""
@@ -282,7 +282,7 @@ def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V
         batch['vp_view_mrc_masks'] = m
         batch['vp_view_probs'] = (p / p.sum(-1, keepdims=True)).astype(np.float32)
         batch['vp_obj_mrc_masks'], batch['vp_obj_probs'] = None, None
-    elif task.startswith('sap'):
+    if task.startswith('sap') or task.startswith('valid_sap_og'):
         # teacher action = a hashed unvisited candidate of the last step (global index) / its local slot, or stop
         ga, la = np.zeros((B,), np.int64), np.zeros((B,), np.int64)
         pickc = integers('pt_sap_pick', (B,), 0, 8, seed)
@@ -292,7 +292,46 @@ def pretrain_batch(B, L=40, O=3, seed=0, task='sap', min_steps=2, max_steps=4, V
             if pickc[i] < 6 and opts:
                 ga[i], la[i] = opts[int(pickc[i]) % len(opts)]
         batch['global_act_labels'], batch['local_act_labels'] = ga, la
+    if reverie:
+        _add_objv1(batch, B, S, V, No, steps, seed, task, n_classes)
     return batch
+
+
+def _add_objv1(batch, B, S, V, No, steps, seed, task, n_classes):
+    """REVERIE pre-training layout (pretrain_src/data/dataset.py get_input + tasks.py collators): every step carries
+    0..No 768-d "objv1" object tokens behind its 36 views; loc / nav-type rows are [views ; objects ; pad] per step,
+    padded over all steps; the viewpoint tokens are [stop] + the LAST step's views and objects."""
+    ol = integers('pt_objv1_lens', (S,), 0, No + 1, seed)
+    last = np.cumsum(steps) - 1
+    ol[0] = No                                   # pad_tensors pads to the longest: keep shapes a function of No
+    free = [i for i in range(1, S) if i not in last]
+    if free:
+        ol[free[0]] = 0                          # an object-free step (the obj_len == 0 branch, vilmodel_reverie.py:559)
+    ol[last] = np.maximum(ol[last], 1)           # the last step of every trajectory has >= 1 object (an OG target exists)
+    Nm = int(ol.max())
+    ov = np.arange(Nm)[None] < ol[:, None]
+    fts = np.where(ov[..., None], uniform('pt_objv1_fts', (S, Nm, 768), seed), 0.0).astype(np.float32)
+    oloc = np.concatenate([_angle_feats('pt_oloc', (S, Nm), seed), uniform('pt_obox', (S, Nm, 3), seed, 0.0, 1.0)], -1)
+    oloc = np.where(ov[..., None], oloc, 0.0).astype(np.float32)
+    batch['traj_obj_img_fts'], batch['traj_vp_obj_lens'] = fts, ol.astype(np.int64)
+    batch['traj_loc_fts'] = np.concatenate([batch['traj_loc_fts'], oloc], 1)
+    batch['traj_nav_types'] = np.concatenate([batch['traj_nav_types'], np.where(ov, 2, 0)], 1).astype(np.int64)
+    lo = ol[last]
+    T = V + int(lo.max()) + 1
+    vp = np.zeros((B, T, 14), np.float32)
+    vp[:, :V + 1] = batch['vp_pos_fts']
+    vp[:, :, :7] = batch['vp_pos_fts'][:, :1, :7]
+    valid = np.arange(T)[None] < (V + 1 + lo)[:, None]
+    batch['vp_pos_fts'] = np.where(valid[..., None], vp, 0.0).astype(np.float32)
+    if task.startswith('mrc'):
+        Lm = int(lo.max())
+        m = (uniform('pt_mrc_opick', (B, Lm), seed, 0.0, 1.0) < 0.3) & (np.arange(Lm)[None] < lo[:, None])
+        m[:, 0] = True
+        p = uniform('pt_mrc_oprobs', (B, Lm, n_classes), seed, 0.0, 1.0) ** 4
+        batch['vp_obj_mrc_masks'] = m
+        batch['vp_obj_probs'] = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+    if task.startswith('og') or task.startswith('valid_sap_og'):
+        batch['obj_labels'] = (integers('pt_og_label', (B,), 0, 1 << 20, seed) % lo).astype(np.int64)
 
 
 # --------------------------------------------------------------------------

@@ -144,9 +144,10 @@ class GlocalTextPathNavCMT(nn.Module):
 
         le = nn.Module()
         le.layer = nn.ModuleList([_bert_layer(h, cfg.intermediate_size, eps) for _ in range(cfg.num_l_layers)])
-        if self.PRETRAIN:   # pretrain_src/model/vilmodel.py:688-690 (present in the state dict, unused in forward)
-            le.instr_act_encoder, le.instr_obj_encoder = _qkv(h), _qkv(h)
-            le.instr_fuse_layernorm = nn.LayerNorm(h, eps=1e-12)
+        if self.PRETRAIN:   # pretrain_src/model/vilmodel.py:688-690 (present in the state dict, unused in forward);
+            if not self.REVERIE:        # the REVERIE pre-training LanguageEncoder is plain (vilmodel_reverie.py:436-457)
+                le.instr_act_encoder, le.instr_obj_encoder = _qkv(h), _qkv(h)
+                le.instr_fuse_layernorm = nn.LayerNorm(h, eps=1e-12)
         else:
             le.act_obj_token_emb = nn.Embedding(1 if self.REVERIE else 2, h)       # unused in forward
             le.instr_actobj_encoder = _qkv(h)

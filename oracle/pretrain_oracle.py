@@ -2,8 +2,11 @@
 
 CPU torch-fp32 restatement of the reference's pre-training model: GlocalTextPathCMT
 (pretrain_src/model/vilmodel.py:716-840) + GlocalTextPathCMTPreTraining heads and losses
-(pretrain_src/model/pretrain_cmt.py:38-294).  Pinned by tests/golden/r2r_pt.npz, produced by the
-reference's own files (tools/make_golden_pt.py).  PT = pretrain_src/model."""
+(pretrain_src/model/pretrain_cmt.py:38-392), and of the REVERIE twin (vilmodel_reverie.py / pretrain_cmt_reverie.py: objv1
+object tokens, MRC object branch, OG).  Pinned by tests/golden/r2r_pt.npz and reverie_pt.npz, produced by the
+reference's own files (tools/make_golden_pt.py).  PT = pretrain_src/model.  `valid_sap_og` has no golden: the
+reference's own call omits the objv2 features and raises (pretrain_cmt.py:337-341); here it is SAP + OG logits of one
+backbone pass, each of which is pinned by its own task's golden."""
 import torch
 import torch.nn.functional as F
 
@@ -46,6 +49,37 @@ def img_embeddings(sd, cfg, b):  # PT/vilmodel.py:497-546
     return torch.split(x, sl, 0), torch.split(b['traj_vp_view_lens'], sl, 0), torch.split(fused, sl, 0)
 
 
+def img_embeddings_reverie(sd, cfg, b):  # PT/vilmodel_reverie.py:520-593
+    V = b['traj_view_img_fts'].shape[1]
+    img = ln(sd, 'img_embeddings.img_layer_norm', lin(sd, 'img_embeddings.img_linear', b['traj_view_img_fts']))
+    obj = objv2_embed(sd, b['traj_objv2_fts'], b['traj_objv2_lens'], b['traj_nav_types'][:, :V], cfg)
+    view = ln(sd, 'img_embeddings.vis_obj_linear.1', lin(sd, 'img_embeddings.vis_obj_linear.0', torch.cat([img, obj], -1)))
+    lens = b['traj_vp_view_lens']
+    if b.get('traj_obj_img_fts') is not None:  # :551-564
+        o1 = ln(sd, 'img_embeddings.obj_reverie_layer_norm', lin(sd, 'img_embeddings.obj_reverie_linear', b['traj_obj_img_fts']))
+        lens = b['traj_vp_view_lens'] + b['traj_vp_obj_lens']
+        x = torch.zeros(view.shape[0], int(lens.max()), view.shape[2])
+        for i in range(view.shape[0]):
+            vl, ol = int(b['traj_vp_view_lens'][i]), int(b['traj_vp_obj_lens'][i])
+            x[i, :vl] = view[i, :vl]
+            x[i, vl:vl + ol] = o1[i, :ol]
+    else:
+        x = view
+    x = x + ln(sd, 'img_embeddings.loc_layer_norm', lin(sd, 'img_embeddings.loc_linear', b['traj_loc_fts'])) \
+        + F.embedding(b['traj_nav_types'], sd['img_embeddings.nav_type_embedding.weight']) \
+        + sd['embeddings.token_type_embeddings.weight'][1][None, None]
+    x = ln(sd, 'img_embeddings.layer_norm', x)
+    x = pano_encoder(sd, 'img_embeddings.pano_encoder', x, seq_masks(lens, x.shape[1]), cfg)
+    w = torch.softmax(torch.tanh(lin(sd, 'img_embeddings.adaptive_pano_attn', x)), 1)
+    fused = (x * w).sum(1)
+    sl = b['traj_step_lens']
+    return torch.split(x, sl, 0), torch.split(lens, sl, 0), torch.split(fused, sl, 0)
+
+
+def _img(sd, cfg, b):
+    return img_embeddings_reverie(sd, cfg, b) if 'img_embeddings.obj_reverie_linear.weight' in sd else img_embeddings(sd, cfg, b)
+
+
 def aggregate_gmap(split_embeds, split_lens, split_fused, b):  # PT/vilmodel.py:597-635
     B = len(split_embeds)
     rows = []
@@ -86,7 +120,7 @@ def vp_input(sd, cfg, se, sl, b):  # PT/vilmodel.py:557-571
 
 def bert_forward(sd, cfg, b, return_gmap=True):  # PT/vilmodel.py:730-779
     txt, tm = text(sd, cfg, b)
-    se, sl, sf = img_embeddings(sd, cfg, b)
+    se, sl, sf = _img(sd, cfg, b)
     ta = ext_neg(tm)
     g = None
     if return_gmap:
@@ -103,7 +137,7 @@ def bert_forward(sd, cfg, b, return_gmap=True):  # PT/vilmodel.py:730-779
 
 def bert_forward_mlm(sd, cfg, b):  # PT/vilmodel.py:782-840
     txt, tm = text(sd, cfg, b)
-    se, sl, sf = img_embeddings(sd, cfg, b)
+    se, sl, sf = _img(sd, cfg, b)
     ta = ext_neg(tm)
     g, gm = gmap_input(sd, cfg, se, sl, sf, b)
     v, vm = vp_input(sd, cfg, se, sl, b)
@@ -132,18 +166,60 @@ def forward(sd_full, cfg, batch, task, compute_loss=True):
     if task.startswith('mrc'):  # :175-228 (R2R: traj_obj_img_fts is None -> views only)
         _, v = bert_forward(sd, cfg, b, return_gmap=False)
         last = [x[-1] for x in torch.split(b['traj_vp_view_lens'], b['traj_step_lens'])]
-        T = int(max(last))
-        ve = torch.zeros(v.shape[0], T, v.shape[-1])
-        for i, n in enumerate(last):
-            ve[i, :int(n)] = v[i, 1:int(n) + 1]
+        ve = _pad_slices([v[i, 1:int(n) + 1] for i, n in enumerate(last)])
         m = b['vp_view_mrc_masks']
         logits = region_head(sd_full, 'image_classifier', ve[m])
         tgt = b['vp_view_probs'][m]
+        ologits = otgt = None
+        if b.get('traj_obj_img_fts') is not None:  # :202-213
+            lo = [x[-1] for x in torch.split(b['traj_vp_obj_lens'], b['traj_step_lens'])]
+            oe = _pad_slices([v[i, int(n) + 1:int(n) + int(k) + 1] for i, (n, k) in enumerate(zip(last, lo))])
+            om = b['vp_obj_mrc_masks']
+            head = 'obj_classifier' if 'obj_classifier.net.0.weight' in sd_full else 'image_classifier'
+            ologits = region_head(sd_full, head, oe[om])
+            otgt = b['vp_obj_probs'][om]
         if not compute_loss:
-            return logits, tgt, None, None
-        return F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+            return logits, tgt, ologits, otgt
+        loss = F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+        if ologits is not None:
+            loss = torch.cat([loss, F.kl_div(F.log_softmax(ologits, -1), otgt, reduction='none').sum(1)], 0)
+        return loss
+    if task.startswith('og'):  # :296-327
+        _, v = bert_forward(sd, cfg, b, return_gmap=False)
+        ol = og_logits(sd_full, b, v)
+        return F.cross_entropy(ol, b['obj_labels'], reduction='none') if compute_loss else ol
+    if task.startswith('valid_sap_og'):  # :329-392 (see the header)
+        g, v = bert_forward(sd, cfg, b)
+        return sap_logits(sd_full, b, g, v) + (og_logits(sd_full, b, v),)
     if task.startswith('sap'):  # :230-294
         g, v = bert_forward(sd, cfg, b)
+        gl, ll, fused = sap_logits(sd_full, b, g, v)
+        if not compute_loss:
+            return gl, ll, fused, b['global_act_labels'], b['local_act_labels']
+        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
+            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
+            + F.cross_entropy(fused, b['global_act_labels'], reduction='none')
+    raise ValueError('invalid task')
+
+
+def _pad_slices(rows):  # PT/ops.py:45-67 pad_tensors_wgrad
+    T = max(r.shape[0] for r in rows)
+    out = torch.zeros(len(rows), T, rows[0].shape[-1])
+    for i, r in enumerate(rows):
+        out[i, :r.shape[0]] = r
+    return out
+
+
+def og_logits(sd_full, b, v):  # PT/pretrain_cmt.py:313-321
+    lv = [x[-1] for x in torch.split(b['traj_vp_view_lens'], b['traj_step_lens'], 0)]
+    lo = [x[-1] for x in torch.split(b['traj_vp_obj_lens'], b['traj_step_lens'], 0)]
+    oe = _pad_slices([v[i, 1 + int(n):1 + int(n) + int(k)] for i, (n, k) in enumerate(zip(lv, lo))])
+    om = seq_masks(torch.stack(lo, 0))
+    return cls_head(sd_full, 'og_head', oe).squeeze(2).masked_fill(~om, float('-inf'))
+
+
+def sap_logits(sd_full, b, g, v):  # PT/pretrain_cmt.py:248-285
+    if True:
         fw = torch.sigmoid(cls_head(sd_full, 'sap_fuse_linear', torch.cat([g[:, 0], v[:, 0]], 1)))
         gl = cls_head(sd_full, 'global_sap_head', g).squeeze(2) * fw
         gl = gl.masked_fill(b['gmap_visited_masks'], float('-inf')).masked_fill(~seq_masks(b['gmap_lens'], g.shape[1]), float('-inf'))
@@ -156,9 +232,4 @@ def forward(sd_full, cfg, batch, task, compute_loss=True):
         ll = ll.masked_fill(nm, float('-inf'))
         fused = fuse_logits(gl, ll, b['gmap_vpids'], b['gmap_visited_masks'],
                             [[None] + list(c[-1]) for c in b['traj_cand_vpids']], 1)
-        if not compute_loss:
-            return gl, ll, fused, b['global_act_labels'], b['local_act_labels']
-        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
-            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
-            + F.cross_entropy(fused, b['global_act_labels'], reduction='none')
-    raise ValueError('invalid task')
+        return gl, ll, fused

@@ -7,7 +7,7 @@ import torch
 
 from dsrg_amd import synth
 from tests import common
-from tests.test_oracle_pt_golden import PT_CFG
+from tests.test_oracle_pt_golden import PT_CFG, PT_CFG_REVERIE, check_reverie_outputs
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,55 @@ def test_pretrain_losses_and_grads(dtype):
                 assert (np.isfinite(t) == fin).all() and np.abs(t[fin] - gg[fin]).max() <= tol
     with pytest.raises(ValueError):
         m(b, 'bogus')
+
+
+def _model_reverie(dtype):
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain_reverie import GlocalTextPathCMTPreTraining
+    m = GlocalTextPathCMTPreTraining(DSRGConfig(**PT_CFG_REVERIE), compute_dtype=dtype)
+    ref = common.load_shapes('reverie_pt')
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref, (set(ref) ^ set(mine))
+    m.load_state_dict(common.synth_sd('reverie_pt'))
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pretrain_reverie_losses_and_grads(dtype):
+    """REVERIE pre-training twin (pretrain_cmt_reverie.py over vilmodel_reverie.py) against the reference's own loss vectors,
+    logits and gradient slices (tests/golden/reverie_pt.npz): mlm, mrc with the object-region branch, sap, og; the same
+    gates as the R2R twin.  valid_sap_og (no golden: the reference's own call raises) must equal sap + og logits."""
+    gold = common.load_gold('reverie_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    m = _model_reverie(dtype)
+    fp32 = dtype == torch.float32
+    named = dict(m.named_parameters())
+    for task in ('mlm', 'mrc', 'sap', 'og'):
+        b = common.to_t(synth.pretrain_batch(B, L, O, seed, task, reverie=True), 'cuda')
+        m.zero_grad()
+        loss = m(b, task, compute_loss=True)
+        g = gold[task + '_loss']
+        assert loss.shape == g.shape
+        err = np.abs(loss.detach().float().cpu().numpy() - g).max()
+        assert err <= (1e-3 if fp32 else 5e-2 * np.abs(g).max()), (task, err)
+        loss.mean().backward()
+        gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+        assert abs(gn - gold[task + '_gradnorm'][0]) <= (2e-3 if fp32 else 5e-2) * gold[task + '_gradnorm'][0], (task, gn)
+        for k, gg in gold.items():
+            if k.startswith(task + '_grad:'):
+                mine = named[k.split(':', 1)[1]].grad.reshape(-1)[:64].float().cpu().numpy()
+                tol = (2e-3 if fp32 else 2.5e-1) * np.abs(gg).max() + 1e-6
+                assert np.abs(mine - gg).max() <= tol, (k, np.abs(mine - gg).max(), np.abs(gg).max())
+        with torch.no_grad():
+            check_reverie_outputs(task, m(b, task, compute_loss=False), gold, 1e-3 if fp32 else 8e-2)
+    b = common.to_t(synth.pretrain_batch(B, L, O, seed, 'valid_sap_og', reverie=True), 'cuda')
+    with torch.no_grad():
+        gl, ll, fl, ol = m(b, 'valid_sap_og')
+        sap, og = m(b, 'sap', compute_loss=False), m(b, 'og', compute_loss=False)
+    tol = 1e-5 if fp32 else 2e-2
+    for a, c in ((gl, sap[0]), (ll, sap[1]), (fl, sap[2]), (ol, og)):
+        fa, fc = torch.isfinite(a), torch.isfinite(c)
+        assert (fa == fc).all() and float((a[fa] - c[fc]).abs().max()) <= tol
 
 
 def test_ddp_wrapper_with_task_dependent_parameters():

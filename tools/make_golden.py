@@ -43,13 +43,13 @@ def import_ft(reverie):
     return mod
 
 
-def import_pt():
+def import_pt(reverie=False):
     for m in [k for k in sys.modules if k == 'model' or k.startswith('model.')]:
         del sys.modules[m]
     sys.path.insert(0, os.path.join(REF, 'pretrain_src'))
     try:
-        mod = importlib.import_module('model.pretrain_cmt')
-        vil = importlib.import_module('model.vilmodel')
+        mod = importlib.import_module('model.pretrain_cmt_reverie' if reverie else 'model.pretrain_cmt')
+        vil = importlib.import_module('model.vilmodel_reverie' if reverie else 'model.vilmodel')
     finally:
         sys.path.pop(0)
     vil.GlocalTextPathCMT.init_weights = lambda self: None
@@ -143,3 +143,6 @@ if __name__ == '__main__':
             run_pt = None
         if run_pt is not None:
             run_pt(import_pt, ref_config, load_synth, a.out)
+    if a.only in ('', 'pt_reverie'):
+        from make_golden_pt import run_pt_reverie
+        run_pt_reverie(import_pt, ref_config, load_synth, a.out)
