@@ -135,46 +135,88 @@ def pmc_traffic(kernel_sig, grids):
     return tot / len(grids), os.path.basename(fetch[-1])
 
 
+def profile_avg_us(kernel_sig):
+    """Average in-step duration (us) of a kernel variant from the newest committed `rocprofv3 --kernel-trace --stats`
+    summary of this bench (profiles/*_bench_c2_kernel_stats.csv: Name, Calls, TotalDurationNs, AverageNs ...), or None."""
+    import csv, glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_bench_c2_kernel_stats.csv')))
+    if not files:
+        return None, None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_sig in r.get('Name', ''):
+            return float(r['AverageNs']) * 1e-3, os.path.basename(files[-1])
+    return None, os.path.basename(files[-1])
+
+
 def gemm_roofline(step_fn, dtype):
-    """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step, then re-issue
-    each launch `rep` times back to back between HIP events on the launch stream; achieved = algorithmic FLOPs of the
-    launches of the dominant tile variant / their measured time."""
+    """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step and time, per
+    kernel variant (tile, ring depth, output type), its launches as they run inside a step: all launches of the variant,
+    in step order, each on its own operands (so A / W / residual come from beyond the XCD L2s, as in the step), captured
+    in a HIP graph on the launch stream and replayed between HIP events.  achieved = algorithmic FLOPs of the dominant
+    variant's launches / that time; the per-launch figure includes the ~1.3 us dependent-launch boundary.  `frac_isolated`
+    is the same launches each replayed 20x back to back on hot operands (round 1's method, reads 30-50 % higher)."""
     from dsrg_amd import kernels
     kernels.GEMM_TRACE = []
     step_fn()
     trace, kernels.GEMM_TRACE = kernels.GEMM_TRACE, None
     torch.cuda.synchronize()
-    rep = 20
     by_tile = {}
     for rec in trace:
-        kernels.gemm_replay(rec)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(rep):
-            kernels.gemm_replay(rec)
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / rep
-        d = by_tile.setdefault((rec['tile'][0], rec['tile'][1], rec['odt']), {'flops': 0.0, 'time': 0.0, 'launches': 0, 'grids': [], 'bytes': 0.0})
-        d['flops'] += rec['flops']; d['time'] += t; d['launches'] += 1; d['grids'].append(rec['wgs'] * 256)
+        d = by_tile.setdefault((rec['tile'], rec['odt']), {'flops': 0.0, 'time': 0.0, 'hot': 0.0, 'launches': 0, 'grids': [], 'bytes': 0.0, 'recs': []})
+        d['flops'] += rec['flops']; d['launches'] += 1; d['grids'].append(rec['wgs'] * 256); d['recs'].append(rec)
         esz, osz = (2 if rec['dt'] == 1 else 4), (4 if rec['odt'] == 0 else 2)
         d['bytes'] += sum((a.M * a.K + a.N * a.K) * esz + a.M * a.N * osz + (a.M * a.N * esz if a.residual else 0) for a in rec['arr'])
+    st = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(st):
+        for d in by_tile.values():
+            for rec in d['recs']:
+                kernels.gemm_replay(rec)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for rec in d['recs']:
+                    kernels.gemm_replay(rec)
+            g.replay(); st.synchronize()
+            rep = 20
+            e0.record(st)
+            for _ in range(rep):
+                g.replay()
+            e1.record(st)
+            e1.synchronize()
+            d['time'] = e0.elapsed_time(e1) * 1e-3 / rep
+            for rec in d['recs']:                       # round 1's figure: each launch 20x back to back, hot operands
+                kernels.gemm_replay(rec)
+                e0.record(st)
+                for _ in range(20):
+                    kernels.gemm_replay(rec)
+                e1.record(st)
+                e1.synchronize()
+                d['hot'] += e0.elapsed_time(e1) * 1e-3 / 20
     dom = max(by_tile, key=lambda k: by_tile[k]['time'])
     d = by_tile[dom]
+    (bm, bn, nst), odt = dom
     peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
-    # (every ring depth of the tile variant: the trace key is the tile, the ring depth is the library's choice per launch)
-    sig = 'gemm_nt_kernel<%s, %s, %d, %d, ' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
-                                               'float' if dom[2] == 0 else 'unsigned short', dom[0], dom[1])
+    sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
+                                                   'float' if odt == 0 else 'unsigned short', bm, bn, nst)
     traffic, src = pmc_traffic(sig, d['grids'])
+    prof_us, prof_src = profile_avg_us(sig)
+    fpl = d['flops'] / d['launches']
     return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
-            'frac': d['flops'] / d['time'] / peak, 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
+            'frac': d['flops'] / d['time'] / peak, 'frac_isolated': d['flops'] / d['hot'] / peak,
+            'frac_profile': (fpl / (prof_us * 1e-6) / peak) if prof_us else None, 'profile_avg_launch_us': prof_us, 'profile_source': prof_src,
+            'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
             'traffic_source': src, 'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
-            'algorithmic_flops_per_launch': d['flops'] / d['launches'],
-            'kernel': 'gemm_nt_kernel<%s,%s,%d,%d,*>' % ('bf16' if dtype == torch.bfloat16 else 'f32', 'f32' if dom[2] == 0 else 'bf16', dom[0], dom[1]),
-            'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
+            'algorithmic_flops_per_launch': fpl,
+            'kernel': sig, 'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
+            'avg_launch_us_isolated': d['hot'] / d['launches'] * 1e6,
+            'timing': 'HIP events around a graph of the variant\'s launches in step order, operands cold (as in the step)',
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
-            'all_gemm_us_per_step': tot_t * 1e6}
+            'all_gemm_us_per_step': tot_t * 1e6,
+            'variants': {'%dx%dx%d/%s' % (k[0] + ('f32' if k[1] == 0 else 'bf16',)): {'launches': v['launches'], 'us': v['time'] * 1e6, 'tflops': v['flops'] / v['time'] / 1e12}
+                         for k, v in by_tile.items()}}
 
 
 PT_TASKS = ('mlm', 'mrc', 'sap')      # mix of PT/config/r2r_pretrain.json, one task per optimisation step

@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HeadTailProblem(C.Structure):
@@ -73,7 +73,8 @@ SIGNATURES = {
     'dsrg_abi_version': (C.c_int, []),
     'dsrg_last_error': (C.c_char_p, []),
     'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
-    'dsrg_gemm_nt_plan': (C.c_int, [C.POINTER(GemmProblem), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'dsrg_gemm_nt_tiled': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _I, _I, _I, _P]),
+    'dsrg_gemm_nt_plan': (C.c_int, [C.POINTER(GemmProblem), _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dsrg_attention_fwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _I, _P, _P, _P,
                                      _I, _I, _I, _I, _F, _P, _F, C.c_uint64, _I, _P]),
     'dsrg_attention_fwd_grouped': (C.c_int, [C.POINTER(AttnProblem), _I, _I, _P, _P, _I, _I, _F, _F, C.c_uint64, _I, _P]),

@@ -393,56 +393,91 @@ struct TileOverride { int bm, bn, nst; bool set; };
 const TileOverride& tile_override() {
   static const TileOverride o = [] {
     TileOverride t{0, 0, 0, false};
-    const char* force = getenv("DSRG_GEMM_TILE");     // "128x128" | "64x128" | "64x64" [x ring depth]
+    const char* force = getenv("DSRG_GEMM_TILE");     // "128x128" | "64x128" | "64x64" ... [x ring depth]
     if (force && sscanf(force, "%dx%dx%d", &t.bm, &t.bn, &t.nst) >= 2) t.set = true;
     return t;
   }();
   return o;
 }
 
-// tile choice: fill >= ~1 wave of the 256 CUs when the problem allows it
-int plan_tiles(GemmArgs& a, int& bm, int& bn, bool big_ok) {
-  auto count = [&](int m, int n) {
-    int tot = 0;
-    for (int i = 0; i < a.nprob; ++i) {
-      a.tile_start[i] = tot;
-      tot += ((a.p[i].M + m - 1) / m) * ((a.p[i].N + n - 1) / n);
+// The tile menu.  Every (bm, bn) has 2x2 waves of (bm/2) x (bn/2); `nst` lists the ring depths built for it (0-terminated,
+// first = default).  The wide tiles exist for bf16 only (fp32 parity mode keeps the three square-ish ones).
+struct TileShape { int bm, bn, nst[4]; bool f32_ok; };
+constexpr TileShape kTiles[] = {
+  {64, 64, {2, 3, 4, 0}, true},   {64, 128, {2, 3, 0, 0}, true},  {64, 192, {3, 0, 0, 0}, false}, {64, 256, {3, 0, 0, 0}, false},
+  {128, 64, {3, 2, 4, 0}, false}, {128, 96, {3, 0, 0, 0}, false}, {128, 128, {2, 3, 0, 0}, true}, {128, 192, {3, 2, 0, 0}, false},
+  {128, 256, {3, 0, 0, 0}, false},
+};
+const TileShape* find_tile(int bm, int bn, bool bf16) {
+  for (const TileShape& t : kTiles)
+    if (t.bm == bm && t.bn == bn && (bf16 || t.f32_ok)) return &t;
+  return nullptr;
+}
+bool tile_has_nst(const TileShape& t, int nst) {
+  for (int i = 0; i < 4 && t.nst[i]; ++i)
+    if (t.nst[i] == nst) return true;
+  return false;
+}
+
+int count_tiles(GemmArgs& a, int m, int n) {
+  int tot = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    a.tile_start[i] = tot;
+    tot += ((a.p[i].M + m - 1) / m) * ((a.p[i].N + n - 1) / n);
+  }
+  a.tile_start[a.nprob] = tot;
+  return tot;
+}
+
+// Tile choice, from measurements on MI355X with operands beyond the XCD L2s, as inside a nav-step (tools/bench_gemm.py
+// --cold --sweep, profiles/r02b_gemm_sweep_cold.txt).  A nav-step GEMM (174..1400 tiles) is bound by
+// per-workgroup latency and by the operand bytes a CU pulls from L2 into LDS, not by the MFMA rate: one round of 200-256
+// large tiles (128x192, 128x256: one workgroup per CU, one wave per SIMD, nothing to hide prologue / epilogue / GELU
+// behind) is 1.5-2.5x SLOWER than 2-4 co-resident workgroups per CU of small tiles on every x-layer shape, so the smallest
+// tile that still gives >= 2 workgroups per CU wins and 128x128 only pays from ~4 rounds of tiles on.  What the sweep
+// added over round 1 is the ring depth: with <= ~2 tiles per CU there are LDS and registers to spare, and a 3- or
+// 4-deep ring is 8-22 % faster (64x64: 10.4 -> 8.1 us at 240 tiles, 11.5 -> 10.6 at 456; K = 3072: 17.1 -> 15.5).
+int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int fbn, int fnst) {
+  nst = 0;
+  if (fbm <= 0) {
+    const TileOverride& ov = tile_override();
+    if (ov.set) { fbm = ov.bm; fbn = ov.bn; fnst = ov.nst; }
+  }
+  if (fbm > 0) {
+    const TileShape* t = find_tile(fbm, fbn, bf16);
+    if (t) {
+      bm = fbm; bn = fbn;
+      nst = tile_has_nst(*t, fnst) ? fnst : t->nst[0];
+      return count_tiles(a, bm, bn);
     }
-    a.tile_start[a.nprob] = tot;
-    return tot;
-  };
-  int maxM = 0;
-  for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
-  const TileOverride& ov = tile_override();
-  if (ov.set && ((ov.bm == 256 && (ov.bn == 128 || ov.bn == 192)) || (ov.bm == 128 && ov.bn == 192) || ((ov.bm == 128 || ov.bm == 64) && (ov.bn == 128 || ov.bn == 64) && !(ov.bm == 128 && ov.bn == 64)))) {
-    bm = ov.bm; bn = ov.bn;
-    bool ok = big_ok || !(bm == 256 || bn == 192);      // the wide tiles exist for bf16 only
-#ifndef DSRG_GEMM_BIG_TILES
-    if (bm == 256) ok = false;
-#endif
-    if (ok) return count(bm, bn);
   }
-  // Measured on MI355X (tools/bench_gemm.py): with a 2-deep ring every tile keeps >= 2 workgroups per CU, and the
-  // mid-size GEMMs of a nav-step (174..1400 tiles) are bound by per-workgroup latency, not by the MFMA rate, so the
-  // smallest tile that still gives >= 2 workgroups per CU wins; 128x128 only pays on >= ~4 rounds of tiles.
-  int minK = 1 << 30;
-  for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
-  if (maxM > 64 && minK >= 512 && count(128, 128) >= 1000) { bm = 128; bn = 128; }
-  else if (maxM > 64 && count(64, 128) >= 512) {
+  int maxM = 0, minK = 1 << 30;
+  for (int i = 0; i < a.nprob; ++i) {
+    maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
+    minK = a.p[i].K < minK ? a.p[i].K : minK;
+  }
+  nst = 2;
+  if (maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) { bm = 128; bn = 128; }
+  else if (maxM > 64 && count_tiles(a, 64, 128) >= 512) {
     // 64x128 keeps 3 workgroups per CU (768 slots): a tile count just above that leaves a near-empty second round,
-    // which one round of 128x128 tiles (2 per CU) beats (panorama FFN-in, 864 tiles: 29.4 -> 23.8 us)
-    const int t = count(64, 128);
-    if (t > 768 && t <= 960 && minK >= 512 && count(128, 128) <= 512) { bm = 128; bn = 128; }
+    // which one round of 128x128 tiles (2 per CU) beats (panorama FFN-in, 864 tiles: 27.9 -> 23.5 us)
+    const int t = count_tiles(a, 64, 128);
+    if (t > 768 && t <= 960 && minK >= 512 && count_tiles(a, 128, 128) <= 512) { bm = 128; bn = 128; }
     else { bm = 64; bn = 128; }
+  } else if (bf16 && maxM > 64 && minK >= 2048 && count_tiles(a, 128, 64) <= 256 && count_tiles(a, 64, 64) > 256) {
+    bm = 128; bn = 64; nst = 4;      // long K, one round of 128x64 tiles (local / panorama FFN-out: 22.2 -> 20.7 us)
+  } else {
+    bm = 64; bn = 64;
+    const int t = count_tiles(a, 64, 64);
+    nst = t <= 320 ? 4 : (t <= 512 ? 3 : 2);
   }
-  else { bm = 64; bn = 64; }
-  return count(bm, bn);
+  return count_tiles(a, bm, bn);
 }
 
 template <typename T, typename OutT>
-int dispatch_tile(GemmArgs& a, hipStream_t s) {
-  int bm, bn;
-  const int tiles = plan_tiles(a, bm, bn, sizeof(T) == 2);
+int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
+  int bm, bn, nst;
+  const int tiles = plan_tiles(a, bm, bn, nst, sizeof(T) == 2, fbm, fbn, fnst);
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
   a.gm = gm_env ? atoi(gm_env) : 4;
   if (a.gm < 1) a.gm = 1;
@@ -464,41 +499,28 @@ int dispatch_tile(GemmArgs& a, hipStream_t s) {
     }
     a.pw[i] = best_pw;
   }
-  // Ring depth: 2 keeps the most workgroups per CU and wins whenever a CU holds >= 2 tiles; with <= ~1.7 tiles per CU
-  // and a long K loop (the FFN-out projections of the panorama / object encoders) a lone workgroup cannot cover the
-  // L2 latency with one stage in flight, and a 3-deep ring is 17-30 % faster (tools/bench_gemm.py).
-  int nst = tile_override().set ? tile_override().nst : 0;
-  if (nst == 0 && bm == 64 && bn == 64 && tiles <= 512) {
-    int minK = 1 << 30;
-    for (int i = 0; i < a.nprob; ++i) minK = a.p[i].K < minK ? a.p[i].K : minK;
-    if (minK >= 1024) nst = 3;
-  }
-#ifdef DSRG_GEMM_BIG_TILES   // experiment: 256-row tiles, one workgroup per CU; reached only through DSRG_GEMM_TILE
+#define DSRG_TILE_CASE(BM_, BN_, NST_) if (bm == BM_ && bn == BN_ && nst == NST_) return launch<T, OutT, BM_, BN_, NST_>(a, tiles, s)
+  DSRG_TILE_CASE(64, 64, 2); DSRG_TILE_CASE(64, 64, 3); DSRG_TILE_CASE(64, 64, 4);
+  DSRG_TILE_CASE(64, 128, 2); DSRG_TILE_CASE(64, 128, 3);
+  DSRG_TILE_CASE(128, 128, 2); DSRG_TILE_CASE(128, 128, 3);
   if constexpr (sizeof(T) == 2) {
-    if (bm == 256 && bn == 192) return launch<T, OutT, 256, 192, 2>(a, tiles, s);
-    if (bm == 256) return launch<T, OutT, 256, 128, 3>(a, tiles, s);
+    DSRG_TILE_CASE(64, 192, 3); DSRG_TILE_CASE(64, 256, 3);
+    DSRG_TILE_CASE(128, 64, 2); DSRG_TILE_CASE(128, 64, 3); DSRG_TILE_CASE(128, 64, 4);
+    DSRG_TILE_CASE(128, 96, 3);
+    DSRG_TILE_CASE(128, 192, 2); DSRG_TILE_CASE(128, 192, 3);
+    DSRG_TILE_CASE(128, 256, 3);
   }
-#endif
-  if constexpr (sizeof(T) == 2) {
-    if (bm == 128 && bn == 192) return launch<T, OutT, 128, 192, 2>(a, tiles, s);
-  }
-  if (bm == 128) {
-    if (nst == 3) return launch<T, OutT, 128, 128, 3>(a, tiles, s);
-    return launch<T, OutT, 128, 128, 2>(a, tiles, s);
-  }
-  if (bn == 128) {
-    if (nst == 3) return launch<T, OutT, 64, 128, 3>(a, tiles, s);
-    return launch<T, OutT, 64, 128, 2>(a, tiles, s);
-  }
-  if (nst == 3) return launch<T, OutT, 64, 64, 3>(a, tiles, s);
-  if (nst == 4) return launch<T, OutT, 64, 64, 4>(a, tiles, s);
-  return launch<T, OutT, 64, 64, 2>(a, tiles, s);
+#undef DSRG_TILE_CASE
+  DSRG_CHECK(false, "dsrg_gemm_nt: no kernel for tile %dx%d ring %d", bm, bn, nst);
+  return DSRG_EINVAL;
 }
+
+int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int out_dtype, int act, int fbm, int fbn, int fnst, void* stream);
 
 }  // namespace
 
-extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int out_dtype,
-                            int act, void* stream) {
+namespace {
+int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int out_dtype, int act, int fbm, int fbn, int fnst, void* stream) {
   DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS, "dsrg_gemm_nt: nproblems=%d out of [1,%d]",
              nproblems, DSRG_MAX_GROUPS);
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_gemm_nt: bad dtype %d", dtype);
@@ -532,19 +554,36 @@ extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, 
   a.nprob = live;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DSRG_BF16) {
-    if (out_dtype == DSRG_F32) return dispatch_tile<bf16_t, float>(a, s);
-    return dispatch_tile<bf16_t, bf16_t>(a, s);
+    if (out_dtype == DSRG_F32) return dispatch_tile<bf16_t, float>(a, s, fbm, fbn, fnst);
+    return dispatch_tile<bf16_t, bf16_t>(a, s, fbm, fbn, fnst);
   }
-  return dispatch_tile<float, float>(a, s);
+  return dispatch_tile<float, float>(a, s, fbm, fbn, fnst);
+}
+}  // namespace
+
+extern "C" int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int out_dtype,
+                            int act, void* stream) {
+  return gemm_entry(problems, nproblems, dtype, out_dtype, act, 0, 0, 0, stream);
 }
 
-extern "C" int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int* bm, int* bn, int* ntiles) {
+extern "C" int dsrg_gemm_nt_tiled(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int out_dtype,
+                                  int act, int bm, int bn, int nst, void* stream) {
+  if (bm > 0) {
+    DSRG_CHECK(find_tile(bm, bn, dtype == DSRG_BF16) != nullptr, "dsrg_gemm_nt_tiled: no %dx%d tile for dtype %d", bm, bn, dtype);
+    DSRG_CHECK(nst == 0 || tile_has_nst(*find_tile(bm, bn, dtype == DSRG_BF16), nst), "dsrg_gemm_nt_tiled: tile %dx%d has no ring depth %d", bm, bn, nst);
+  }
+  return gemm_entry(problems, nproblems, dtype, out_dtype, act, bm, bn, nst, stream);
+}
+
+extern "C" int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, int* bm, int* bn, int* ntiles, int* nst_out) {
   DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS && bm && bn && ntiles, "dsrg_gemm_nt_plan: bad arguments");
   GemmArgs a;
   a.nprob = 0;
   for (int i = 0; i < nproblems; ++i)
     if (problems[i].M > 0 && problems[i].N > 0) a.p[a.nprob++] = problems[i];
   *bm = *bn = *ntiles = 0;
-  if (a.nprob) *ntiles = plan_tiles(a, *bm, *bn, dtype == DSRG_BF16);
+  int nst = 0;
+  if (a.nprob) *ntiles = plan_tiles(a, *bm, *bn, nst, dtype == DSRG_BF16, 0, 0, 0);
+  if (nst_out) *nst_out = nst;
   return DSRG_OK;
 }

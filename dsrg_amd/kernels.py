@@ -75,9 +75,10 @@ def _rows(t):
     return M, ld
 
 
-def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None):
+def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None):
     """problems: list of (x [..,K], w [N,K], bias fp32 [N] | None, residual [..,N] | None).
-    Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32)."""
+    Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32).  tile=(bm, bn, nst) pins the block tile
+    (dsrg_gemm_nt_tiled; tuning only)."""
     lib = _lib.load()
     n = len(problems)
     arr = (_lib.GemmProblem * n)()
@@ -108,12 +109,15 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None):
         arr[i] = _lib.GemmProblem(_p(x), _p(w), _p(b), _p(r), _p(out), M, N, K, lda, w.stride(0), ldr, ldc)
         res.append(out)
     odt = F32 if out_f32 else dt
+    if tile is not None:
+        _lib.check(lib.dsrg_gemm_nt_tiled(arr, n, dt, odt, act, tile[0], tile[1], tile[2] if len(tile) > 2 else 0, _stream()), 'dsrg_gemm_nt_tiled')
+        return res
     _lib.check(lib.dsrg_gemm_nt(arr, n, dt, odt, act, _stream()), 'dsrg_gemm_nt')
     if GEMM_TRACE is not None:
-        bm, bn, nt = C.c_int(), C.c_int(), C.c_int()
-        lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt))
+        bm, bn, nt, nst = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst))
         keep = [t for p in problems for t in p if t is not None] + res
-        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value),
+        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value),
                            'wgs': nt.value, 'flops': sum(2.0 * a.M * a.N * a.K for a in arr), 'keep': keep})
     return res
 

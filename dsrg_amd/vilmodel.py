@@ -478,7 +478,10 @@ class GlocalTextPathNavCMT(nn.Module):
                         feat=loc_fts.float().reshape(B * T, -1).contiguous(), Wf=W['loc.w'], bf=W['loc.b'],
                         lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=nav_types.reshape(-1),
                         vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b'])).view(B, T, H)
-        return self._drop(x, getattr(cfg, 'image_dropout_prob', cfg.hidden_dropout_prob) if self.REVERIE else cfg.hidden_dropout_prob)
+        # FT REVERIE: nn.Dropout(config.image_dropout_prob) (vilmodel_reverie.py:588); R2R and both pre-training twins:
+        # hidden_dropout_prob (vilmodel.py:576, PT/vilmodel_reverie.py:514)
+        ft_reverie = self.REVERIE and not self.PRETRAIN
+        return self._drop(x, getattr(cfg, 'image_dropout_prob', cfg.hidden_dropout_prob) if ft_reverie else cfg.hidden_dropout_prob)
 
     def _concat2(self, a_fn, b_fn, B, V, ha, hb, device):
         """[a | b] along the feature dim.  No-grad: both producers write straight into one buffer."""

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 8
+#define DSRG_ABI_VERSION 9
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -49,10 +49,17 @@ typedef struct {
 } dsrg_gemm_problem_t;
 int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
                  int act, void* stream);
-/* Which block tile (bm x bn) and how many workgroups dsrg_gemm_nt would use for these problems (host-only
- * query, no launch; used by bench.py to attribute measured durations to a kernel variant). */
+/* Which block tile (bm x bn), how many workgroups and which LDS ring depth (nst, may be NULL) dsrg_gemm_nt would use
+ * for these problems (host-only query, no launch; used by bench.py to attribute measured durations to a kernel variant). */
 int dsrg_gemm_nt_plan(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int* bm, int* bn,
-                      int* ntiles);
+                      int* ntiles, int* nst);
+/* dsrg_gemm_nt with the block tile (bm x bn) and LDS ring depth `nst` chosen by the caller instead of the library's
+ * plan (bm = 0: the plan; nst = 0: the tile's default depth).  Same reference sites as dsrg_gemm_nt; exists so that a
+ * host can tune / pin the tile per call without process-wide state (tools/bench_gemm.py --sweep).  Tiles built:
+ * 64x64, 64x128, 128x128 (both dtypes); bf16 only: 64x192, 64x256, 128x64, 128x96, 128x192, 128x256.  DSRG_EINVAL for
+ * a tile / depth that is not built. */
+int dsrg_gemm_nt_tiled(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
+                       int act, int bm, int bn, int nst, void* stream);
 
 /* ---- fused short-sequence attention ------------------------------------------------------------
  * O[b,q,h,:] = softmax_k( scale·Q[b,q,h,:]·K[b,k,h,:] + mask_term(b,k) + sprel(b,q,k) ) · V[b,k,h,:]
