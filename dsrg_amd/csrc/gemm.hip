@@ -51,7 +51,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <typename T, typename OutT, int BM, int BN, int NST>
+// FUSE: the LayerNorm-fusion epilogue (include/dsrg_hip.h, dsrg_gemm_problem_t): built for the 64x64 tile only, launched
+// only when a problem of the group asks for it, so the plain kernels carry none of its registers.
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   GEMM_STAMP(0);
   constexpr int PER16 = Elem<T>::PER16;
@@ -125,6 +127,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 #pragma unroll
       for (int e = 0; e < CW; ++e)
         if (n + e < N) bv[e] = bias[n + e];
+    }
+  }
+
+  // ---- FUSE: this thread's share of the LayerNorm partials of its tile's rows (row = tid % BM, every 4th partial from
+  // tid / BM on), issued here with everything else that can hide behind the first stage; they are summed after the K loop.
+  constexpr int SP = 4;                               // partial loads per thread and set: a_np, r_np <= 16
+  float2 pa[FUSE ? SP : 1], pr[FUSE ? SP : 1];
+  if constexpr (FUSE) {
+    static_assert(BM == 64, "the fused epilogue assumes 4 threads per tile row");
+    const int srow = min(m0 + (tid & (BM - 1)), M - 1), sg = tid / BM;
+#pragma unroll
+    for (int j = 0; j < SP; ++j) { pa[j] = make_float2(0.f, 0.f); pr[j] = make_float2(0.f, 0.f); }
+    if (P.a_stats) {
+      const float2* ps_ = reinterpret_cast<const float2*>(P.a_stats) + (size_t)srow * P.a_np;
+#pragma unroll
+      for (int j = 0; j < SP; ++j) pa[j] = ps_[min(sg + 4 * j, P.a_np - 1)];
+    }
+    if (P.r_stats) {
+      const float2* ps_ = reinterpret_cast<const float2*>(P.r_stats) + (size_t)srow * P.r_np;
+#pragma unroll
+      for (int j = 0; j < SP; ++j) pr[j] = ps_[min(sg + 4 * j, P.r_np - 1)];
+    }
+  }
+  // ... and the per-column vectors of this thread's CW output columns (row sums of the folded weight; residual gamma / beta)
+  float c1v[FUSE ? CW : 1], rgv[FUSE ? CW : 1], rbv[FUSE ? CW : 1];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int e = 0; e < CW; ++e) { c1v[e] = 0.f; rgv[e] = 1.f; rbv[e] = 0.f; }
+    if (n + CW - 1 < N) {
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        if (P.a_stats) { const float4 t4 = *reinterpret_cast<const float4*>(P.a_c1 + n + 4 * h); c1v[4 * h] = t4.x; c1v[4 * h + 1] = t4.y; c1v[4 * h + 2] = t4.z; c1v[4 * h + 3] = t4.w; }
+        if (P.r_stats) {
+          const float4 g4 = *reinterpret_cast<const float4*>(P.r_gamma + n + 4 * h), b4 = *reinterpret_cast<const float4*>(P.r_beta + n + 4 * h);
+          rgv[4 * h] = g4.x; rgv[4 * h + 1] = g4.y; rgv[4 * h + 2] = g4.z; rgv[4 * h + 3] = g4.w;
+          rbv[4 * h] = b4.x; rbv[4 * h + 1] = b4.y; rbv[4 * h + 2] = b4.z; rbv[4 * h + 3] = b4.w;
+        }
+      }
     }
   }
 
@@ -309,9 +349,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
       if (r < EROWS && m < M) rres[ps] = *reinterpret_cast<const RawRes*>(Rp + (size_t)m * P.ldr + n);
     }
   }
+  // FUSE: the 4 threads of a tile row exchange their partial sums through LDS, in the part of the drained ring behind the
+  // fp32 image (no extra LDS, no extra barrier): written next to the image, read back by every thread for its own rows
+  float2* lnpart = reinterpret_cast<float2*>(smem + BM * BN * 4);        // [2 sets][4 groups][BM]
+  float2 sa = make_float2(0.f, 0.f), sr2 = make_float2(0.f, 0.f);
+  if constexpr (FUSE) {
+    static_assert(EPASS == 1, "fused epilogue: one pass");
+    static_assert(BM * BN * 4 + 2 * 4 * BM * 8 <= NST * TILE_BYTES, "the partial tables must fit the ring behind the image");
+    const int sg = tid / BM;
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {                 // fixed order: the sums do not depend on the schedule
+      if (sg + 4 * j < P.a_np) { sa.x += pa[j].x; sa.y += pa[j].y; }
+      if (sg + 4 * j < P.r_np) { sr2.x += pr[j].x; sr2.y += pr[j].y; }
+    }
+  }
 #pragma unroll
   for (int ep = 0; ep < EPASS; ++ep) {
     __syncthreads();                                // every wave is done reading the last stage / the previous image
+    if constexpr (FUSE) {
+      lnpart[(0 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sa;
+      lnpart[(1 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sr2;
+    }
     if (EPASS == 1 || wm == ep) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -330,25 +388,62 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
         const int r = orow0 + ps * RPP;
         const int m = m0 + ep * EROWS + r;
         if (r >= EROWS || m >= M) break;
+        float2 msa = make_float2(0.f, 1.f), msr = make_float2(0.f, 1.f);   // (mean, rstd) of this row: A operand over K, residual over N
+        if constexpr (FUSE) {
+          float2 t0 = make_float2(0.f, 0.f), t1 = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float2 u0 = lnpart[(0 * 4 + g4) * BM + r], u1 = lnpart[(1 * 4 + g4) * BM + r];
+            t0.x += u0.x; t0.y += u0.y; t1.x += u1.x; t1.y += u1.y;
+          }
+          const float ia = 1.0f / (float)K, ir = 1.0f / (float)N;
+          msa.x = t0.x * ia; msa.y = rsqrtf(fmaxf(t0.y * ia - msa.x * msa.x, 0.f) + P.ln_eps);
+          msr.x = t1.x * ir; msr.y = rsqrtf(fmaxf(t1.y * ir - msr.x * msr.x, 0.f) + P.ln_eps);
+        }
         float v[CW];
 #pragma unroll
         for (int h = 0; h < CW / 4; ++h) {
           const int ch = oc * (CW / 4) + h;           // 4-float chunk of the image row
           const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((ch ^ (r & 7)) << 2));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * h + e] = apply_act<sizeof(OutT) == 2>(a4[e] + bv[4 * h + e], act);
+          for (int e = 0; e < 4; ++e) {
+            float x = a4[e];
+            if constexpr (FUSE) {
+              if (P.a_stats) x = msa.y * (x - msa.x * c1v[4 * h + e]);
+            }
+            v[4 * h + e] = apply_act<sizeof(OutT) == 2>(x + bv[4 * h + e], act);
+          }
         }
         if (vec) {
           if (Rp) {
             RawRes raw;
             if constexpr (PRE_RES) raw = rres[ps];
             else raw = *reinterpret_cast<const RawRes*>(Rp + (size_t)m * P.ldr + n);
+            float rv[CW];
             if constexpr (CW == 8) {
               const float4 r0 = raw4(make_uint2(raw.x, raw.y)), r1 = raw4(make_uint2(raw.z, raw.w));
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+              rv[0] = r0.x; rv[1] = r0.y; rv[2] = r0.z; rv[3] = r0.w; rv[4] = r1.x; rv[5] = r1.y; rv[6] = r1.z; rv[7] = r1.w;
             } else {
               const float4 rr = raw4(raw);
-              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+              rv[0] = rr.x; rv[1] = rr.y; rv[2] = rr.z; rv[3] = rr.w;
+            }
+            if constexpr (FUSE) {
+              if (P.r_stats) {
+#pragma unroll
+                for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - msr.x) * msr.y * rgv[e] + rbv[e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < CW; ++e) v[e] += rv[e];
+          }
+          if constexpr (FUSE) {
+            if (P.stats_out) {        // partial (sum, sum of squares) of this row over the tile's BN columns, from the fp32 values
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int e = 0; e < CW; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+#pragma unroll
+              for (int o = 1; o < CPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+              if (oc == 0) reinterpret_cast<float2*>(P.stats_out)[(size_t)m * ((N + 63) / 64) + tn] = make_float2(s1, s2);
             }
           }
           if constexpr (CW == 8) {
@@ -378,12 +473,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 #endif
 }
 
-template <typename T, typename OutT, int BM, int BN, int NST>
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
-  constexpr int smem = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
-  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST>), smem);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST>), dim3(total_tiles), dim3(256), smem, s, a);
+  constexpr int smem_main = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
+  constexpr int smem = smem_main;
+  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE>), smem);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE>), dim3(total_tiles), dim3(256), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
   return DSRG_OK;
 }
@@ -429,14 +525,19 @@ int count_tiles(GemmArgs& a, int m, int n) {
   return tot;
 }
 
-// Tile choice, from measurements on MI355X with operands beyond the XCD L2s, as inside a nav-step (tools/bench_gemm.py
-// --cold --sweep, profiles/r02b_gemm_sweep_cold.txt).  A nav-step GEMM (174..1400 tiles) is bound by
-// per-workgroup latency and by the operand bytes a CU pulls from L2 into LDS, not by the MFMA rate: one round of 200-256
-// large tiles (128x192, 128x256: one workgroup per CU, one wave per SIMD, nothing to hide prologue / epilogue / GELU
-// behind) is 1.5-2.5x SLOWER than 2-4 co-resident workgroups per CU of small tiles on every x-layer shape, so the smallest
-// tile that still gives >= 2 workgroups per CU wins and 128x128 only pays from ~4 rounds of tiles on.  What the sweep
-// added over round 1 is the ring depth: with <= ~2 tiles per CU there are LDS and registers to spare, and a 3- or
-// 4-deep ring is 8-22 % faster (64x64: 10.4 -> 8.1 us at 240 tiles, 11.5 -> 10.6 at 456; K = 3072: 17.1 -> 15.5).
+// Tile choice, from measurements on MI355X (profiles/r02b_gemm_sweep_cold.txt, r02d_plan_ab.txt).
+//  * One launch at a time on operands beyond the XCD L2s (tools/bench_gemm.py --cold --sweep): a nav-step GEMM (174..1400
+//    tiles of 64x64) is bound by per-workgroup latency and by the operand bytes a CU pulls from L2 into LDS (~36 B/clk per
+//    CU), not by the MFMA rate.  One round of 200-256 large tiles (128x192, 128x256: one workgroup per CU, one wave per
+//    SIMD, nothing to hide prologue / epilogue / GELU behind) is 1.5-2.5x SLOWER than 2-4 co-resident workgroups of small
+//    tiles on every x-layer shape; per launch the best tile is 64x64 for N = 768, 64x128 / 128x64 for N = 2304 and 128x128
+//    for the local FFN-in, each with the ring depth that the tile count leaves LDS for.
+//  * Inside the step the ranking changes: the captured graph runs two chains of launches side by side (global / local
+//    branch, object / view encoder), and what counts is how many workgroups of BOTH kernels a CU holds.  A/B of the whole
+//    step on one box (bench.py, ms per step): round 1's plan 1.233 | per-launch-best tiles and depths 1.255 | 64x64 with a
+//    3-deep ring everywhere 1.201 | 64x128x2 everywhere 1.356 | 128x64x3 1.253 | 128x128x2 1.535.  So: 64x64, 3-deep ring
+//    (48 KiB: three workgroups per CU), 2-deep from 1024 tiles on (4+ rounds: occupancy hides the latency), and 128x128
+//    only for the big once-per-episode GEMMs (text K/V panel, >= 1000 tiles of 128x128: 164 -> 128 us).
 int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int fbn, int fnst) {
   nst = 0;
   if (fbm <= 0) {
@@ -456,20 +557,12 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
     minK = a.p[i].K < minK ? a.p[i].K : minK;
   }
-  nst = 2;
-  if (maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) { bm = 128; bn = 128; }
-  else if (maxM > 64 && count_tiles(a, 64, 128) >= 512) {
-    // 64x128 keeps 3 workgroups per CU (768 slots): a tile count just above that leaves a near-empty second round,
-    // which one round of 128x128 tiles (2 per CU) beats (panorama FFN-in, 864 tiles: 27.9 -> 23.5 us)
-    const int t = count_tiles(a, 64, 128);
-    if (t > 768 && t <= 960 && minK >= 512 && count_tiles(a, 128, 128) <= 512) { bm = 128; bn = 128; }
-    else { bm = 64; bn = 128; }
-  } else if (bf16 && maxM > 64 && minK >= 2048 && count_tiles(a, 128, 64) <= 256 && count_tiles(a, 64, 64) > 256) {
-    bm = 128; bn = 64; nst = 4;      // long K, one round of 128x64 tiles (local / panorama FFN-out: 22.2 -> 20.7 us)
-  } else {
+  bool fuse = false;
+  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
+  if (!fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) { bm = 128; bn = 128; nst = 2; }
+  else {
     bm = 64; bn = 64;
-    const int t = count_tiles(a, 64, 64);
-    nst = t <= 320 ? 4 : (t <= 512 ? 3 : 2);
+    nst = count_tiles(a, 64, 64) > 1024 ? 2 : 3;
   }
   return count_tiles(a, bm, bn);
 }
@@ -498,6 +591,13 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
       if (best < 0 || rows < best) { best = rows; best_pw = pw; }
     }
     a.pw[i] = best_pw;
+  }
+  bool fuse = false;
+  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
+  if (fuse) {
+    DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: the LayerNorm-fusion epilogue exists for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
+    if (nst == 2) return launch<T, OutT, 64, 64, 2, true>(a, tiles, s);
+    return launch<T, OutT, 64, 64, 3, true>(a, tiles, s);
   }
 #define DSRG_TILE_CASE(BM_, BN_, NST_) if (bm == BM_ && bn == BN_ && nst == NST_) return launch<T, OutT, BM_, BN_, NST_>(a, tiles, s)
   DSRG_TILE_CASE(64, 64, 2); DSRG_TILE_CASE(64, 64, 3); DSRG_TILE_CASE(64, 64, 4);
@@ -548,6 +648,17 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
     DSRG_CHECK(p.ldc >= p.N && (!p.residual || p.ldr >= p.N), "dsrg_gemm_nt: problem %d ldc/ldr < N", i);
     DSRG_CHECK(((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.residual & 7) == 0 && ((uintptr_t)p.bias & 15) == 0,
                "dsrg_gemm_nt: problem %d C/residual/bias misaligned", i);
+    if (p.a_stats || p.r_stats || p.stats_out) {   // LayerNorm fusion: whole 16-byte column groups only, partials 8-byte aligned
+      DSRG_CHECK(p.N % 8 == 0 && p.ldc % 8 == 0 && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0)),
+                 "dsrg_gemm_nt: problem %d: LayerNorm fusion needs N, ldc, ldr multiples of 8 and a 16-byte aligned residual", i);
+      DSRG_CHECK(!p.a_stats || (p.a_c1 && p.a_np >= 1 && p.a_np <= 16 && ((uintptr_t)p.a_stats & 7) == 0 && ((uintptr_t)p.a_c1 & 15) == 0),
+                 "dsrg_gemm_nt: problem %d: a_stats needs a_c1 and 1 <= a_np <= 16", i);
+      DSRG_CHECK(!p.r_stats || (p.residual && p.r_gamma && p.r_beta && p.r_np >= 1 && p.r_np <= 16 && ((uintptr_t)p.r_stats & 7) == 0 &&
+                                ((uintptr_t)p.r_gamma & 15) == 0 && ((uintptr_t)p.r_beta & 15) == 0),
+                 "dsrg_gemm_nt: problem %d: r_stats needs a residual, r_gamma, r_beta and 1 <= r_np <= 16", i);
+      DSRG_CHECK(!p.stats_out || (p.N % 64 == 0 && ((uintptr_t)p.stats_out & 7) == 0), "dsrg_gemm_nt: problem %d: stats_out needs N %% 64 == 0", i);
+      DSRG_CHECK(p.ln_eps > 0.f || (!p.a_stats && !p.r_stats), "dsrg_gemm_nt: problem %d: ln_eps must be positive", i);
+    }
     a.p[live++] = p;
   }
   if (live == 0) return DSRG_OK;

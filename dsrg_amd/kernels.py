@@ -75,10 +75,14 @@ def _rows(t):
     return M, ld
 
 
-def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None):
+def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=None):
     """problems: list of (x [..,K], w [N,K], bias fp32 [N] | None, residual [..,N] | None).
     Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32).  tile=(bm, bn, nst) pins the block tile
-    (dsrg_gemm_nt_tiled; tuning only)."""
+    (dsrg_gemm_nt_tiled; tuning only).
+    fuse: optional list (one entry per problem, None = plain) of dicts for the LayerNorm-fusion epilogue of
+    dsrg_gemm_problem_t: 'a_stats': (partials [M, K/64, 2] fp32, c1 [N] fp32) - x holds an un-normalised row and w / bias
+    are the gamma-folded weight and beta-folded bias; 'r_stats': (partials [M, N/64, 2], gamma [N], beta [N]) - the residual
+    is un-normalised; 'stats_out': fp32 [M, N/64, 2] to receive this launch's partials; 'eps'."""
     lib = _lib.load()
     n = len(problems)
     arr = (_lib.GemmProblem * n)()
@@ -107,6 +111,27 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None):
         if Mo != M or w.stride(1) != 1:
             raise _lib.DsrgHipError('gemm: bad out rows / weight layout')
         arr[i] = _lib.GemmProblem(_p(x), _p(w), _p(b), _p(r), _p(out), M, N, K, lda, w.stride(0), ldr, ldc)
+        f = fuse[i] if fuse is not None else None
+        if f:
+            g = arr[i]
+            g.ln_eps = float(f.get('eps', 1e-12))
+            if f.get('a_stats') is not None:
+                st, c1 = f['a_stats']
+                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, K // 64, 2) or K % 64 or c1.shape != (N,) \
+                        or c1.dtype != torch.float32 or not c1.is_contiguous():
+                    raise _lib.DsrgHipError('gemm: a_stats must be contiguous fp32 [M, K/64, 2] with c1 fp32 [N]')
+                g.a_stats, g.a_c1, g.a_np = _p(st), _p(c1), K // 64
+            if f.get('r_stats') is not None:
+                st, ga, be = f['r_stats']
+                if r is None or st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, N // 64, 2) or N % 64 \
+                        or any(t.shape != (N,) or t.dtype != torch.float32 or not t.is_contiguous() for t in (ga, be)):
+                    raise _lib.DsrgHipError('gemm: r_stats must be contiguous fp32 [M, N/64, 2] with gamma, beta fp32 [N] and a residual')
+                g.r_stats, g.r_gamma, g.r_beta, g.r_np = _p(st), _p(ga), _p(be), N // 64
+            if f.get('stats_out') is not None:
+                st = f['stats_out']
+                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, N // 64, 2) or N % 64:
+                    raise _lib.DsrgHipError('gemm: stats_out must be contiguous fp32 [M, N/64, 2]')
+                g.stats_out = _p(st)
         res.append(out)
     odt = F32 if out_f32 else dt
     if tile is not None:
@@ -116,7 +141,7 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None):
     if GEMM_TRACE is not None:
         bm, bn, nt, nst = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst))
-        keep = [t for p in problems for t in p if t is not None] + res
+        keep = [t for p in problems for t in p if t is not None] + res + [fuse]
         GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value),
                            'wgs': nt.value, 'flops': sum(2.0 * a.M * a.N * a.K for a in arr), 'keep': keep})
     return res

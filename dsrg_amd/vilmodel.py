@@ -179,6 +179,9 @@ class GlocalTextPathNavCMT(nn.Module):
         self._side_stream, self.overlap_streams, self._fork_depth = None, True, 0
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams (3.6 % faster than grouped launches at R2R shapes; 0 = grouped)
         self.split_when_eager = False          # bench.py sets it to trace the captured schedule's launches eagerly
+        # inference: the LayerNorms inside the x-layers are folded into the neighbouring GEMM epilogues (_x_layers_fused)
+        self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '1') == '1'
+        self._fold = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
     # ---------------------------------------------------------------- construction helpers
@@ -233,7 +236,7 @@ class GlocalTextPathNavCMT(nn.Module):
         return model.eval()
 
     def invalidate_caches(self):
-        self._wcache, self._kv_cache, self._wplan, self._wgrad = None, None, None, None
+        self._wcache, self._kv_cache, self._wplan, self._wgrad, self._fold = None, None, None, None, None
         self._wtoken = object()
 
     def _wplan_token(self):
@@ -586,10 +589,88 @@ class GlocalTextPathNavCMT(nn.Module):
                     src[i, j] = slot.get(vp, -2)
         return src, bw
 
+    def _folded(self, W, lin_key, ln_key):
+        """(W * diag(gamma), its row sums c1, bias + W beta) of the projection `lin_key` applied to LN_{ln_key}(y): the
+        operands of the a_stats form of dsrg_gemm_nt (include/dsrg_hip.h).  Derived from the packed weights, cached with them."""
+        if self._fold is None or self._fold[0] is not W:
+            self._fold = (W, {})
+        F = self._fold[1]
+        k = lin_key + '<' + ln_key
+        if k not in F:
+            w, g, b = W[lin_key + '.w'], W[ln_key + '.g'], W[ln_key + '.b']
+            wf = (w.float() * g[None]).to(w.dtype).contiguous()
+            F[k] = (wf, wf.float().sum(1).contiguous(), (W[lin_key + '.b'] + w.float() @ b).contiguous())
+        return F[k]
+
+    def _x_layers_fused(self, W, kv, txt_masks, feats, masks, dists, brs):
+        """_x_layers without its 3 LayerNorm launches per layer and branch (inference).  A post-LN sub-block leaves its
+        UN-normalised sum y (compute dtype) plus per-row partial statistics written by the same GEMM launch; the projections
+        that read LN(y) run on y with gamma folded into the weight and the mean / rstd correction in their epilogue, and the
+        next dense + residual normalises its residual on the fly (dsrg_gemm_problem_t: stats_out / a_stats / r_stats).
+        Only the last layer's output is materialised by a LayerNorm launch.  Same arithmetic in real numbers
+        (vilmodel.py:173-177, 213-217, 454-469); in bf16 y is rounded once before instead of after the normalisation."""
+        cfg, cd = self.config, self.compute_dtype
+        H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
+        n = len(brs)
+        sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
+        dev = feats[0].device
+        Ms = [f.shape[0] * f.shape[1] for f in feats]
+        new_stats = lambda: [torch.empty(m, H // 64, 2, device=dev, dtype=torch.float32) for m in Ms]
+        # per branch: (tensor, stats | None, LayerNorm key | None): a materialised input, or an un-normalised y
+        cur = [(f, None, None) for f in feats]
+
+        def proj(lin, act=ACT_NONE):      # projection of LN(cur)
+            probs, fz = [], []
+            for j in range(n):
+                t, st, lnk = cur[j]
+                if st is None:
+                    probs.append((t, W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], None)); fz.append(None)
+                else:
+                    wf, c1, bf_ = self._folded(W, ks[j] + lin, lnk)
+                    probs.append((t, wf, bf_, None)); fz.append({'a_stats': (st, c1), 'eps': eps})
+            return K.gemm(probs, act, False, fuse=fz)
+
+        def dense_res(lin, hs, out_stats, out_f32=False):      # dense(h) + LN(cur)
+            probs, fz = [], []
+            for j in range(n):
+                t, st, lnk = cur[j]
+                d = {'eps': eps}
+                if st is not None:
+                    d['r_stats'] = (st, W[lnk + '.g'], W[lnk + '.b'])
+                if out_stats is not None:
+                    d['stats_out'] = out_stats[j]
+                probs.append((hs[j], W[ks[j] + lin + '.w'], W[ks[j] + lin + '.b'], t)); fz.append(d)
+            return K.gemm(probs, ACT_NONE, out_f32, fuse=fz)
+
+        for i in range(nl):
+            ks = ['x.%s.%d' % (b, i) for b in brs]
+            q = proj('.cq')
+            offs = [((('g', 'l').index(brs[j]) * nl + i) * 2) * H for j in range(n)]
+            a = Fn.attention_grouped([(q[j], kv[..., o:o + H], kv[..., o + H:o + 2 * H], txt_masks, None) for j, o in enumerate(offs)],
+                                     nh, MASK_NEG10000)
+            st = new_stats()
+            y = dense_res('.co', a, st)
+            cur = [(y[j], st[j], ks[j] + '.cln') for j in range(n)]
+            qkv = proj('.qkv')
+            a = Fn.attention_grouped([(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], masks[j],
+                                       dists if brs[j] == 'g' else None) for j in range(n)], nh, MASK_NEG10000, sw, sb)
+            st = new_stats()
+            y = dense_res('.so', a, st)
+            cur = [(y[j], st[j], ks[j] + '.sln') for j in range(n)]
+            inter = proj('.ff1', ACT_GELU)
+            if i == nl - 1:
+                z = dense_res('.ff2', inter, None, out_f32=True)
+                return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd)
+            st = new_stats()
+            y = dense_res('.ff2', inter, st)
+            cur = [(y[j], st[j], ks[j] + '.fln') for j in range(n)]
+
     def _x_layers(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
         """The CrossmodalEncoders of the branches in `brs` (global 'g', local 'l') in lock-step: every GEMM is one
         grouped launch over the branches (vilmodel.py:540-549, 454-469)."""
         cfg = self.config
+        if self.fuse_ln and not torch.is_grad_enabled() and not self.training and cfg.hidden_size % 64 == 0 and cfg.hidden_size <= 1024:
+            return self._x_layers_fused(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs)
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)

@@ -46,6 +46,23 @@ typedef struct {
   const void* A; const void* W; const float* bias; const void* residual; void* C;
   int32_t M, N, K;
   int32_t lda, ldw, ldr, ldc;
+  /* Optional LayerNorm fusion (all NULL / 0 = plain GEMM).  A post-LN block  x1 = LN(y),  y = dense(..) + residual
+   * (BertSelfOutput / BertOutput, FT/vilmodel.py:173-177, 213-217) followed by projections of x1 needs no standalone
+   * LayerNorm launch and no fp32 copy of y:
+   *  - stats_out: float2 [M, ceil(N/64)]: the launch that produces y also writes, per row and per 64-column tile, the
+   *    partial (sum, sum of squares) of the fp32 values it stores (N % 64 == 0; forces the 64-column tile);
+   *  - a_stats / a_np / a_c1: A holds the UN-normalised y [M,K] of a previous launch and a_stats its partials
+   *    (a_np per row, a_np = K/64 <= 16).  With W' = W * diag(gamma) as the weight, a_c1[n] = sum_k W'[n,k] and
+   *    bias[n] = b[n] + sum_k beta[k] W[n,k] the epilogue computes  rstd_m * (acc - mu_m * a_c1[n]) + bias[n]
+   *    = LN(y) W^T + b  (exact in real arithmetic; mu, rstd over the K columns of A with ln_eps);
+   *  - r_stats / r_np / r_gamma / r_beta: the residual holds an un-normalised y' [M,N] and r_stats its partials; the
+   *    residual added is LN(y')[m,n] = (y' - mu'_m) * rstd'_m * r_gamma[n] + r_beta[n]. */
+  const float* a_stats; const float* a_c1;
+  const float* r_stats; const float* r_gamma; const float* r_beta;
+  float* stats_out;
+  int32_t a_np, r_np;
+  float ln_eps;
+  int32_t reserved_;
 } dsrg_gemm_problem_t;
 int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
                  int act, void* stream);

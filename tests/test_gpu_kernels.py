@@ -44,6 +44,57 @@ def test_gemm(K, dtype, M, N, K_, act, res, of32):
     assert err <= tol * max(1.0, scale), (err, tol, scale)
 
 
+def _ln_fold(w, b, gamma, beta, dtype):
+    """(W * gamma in the storage dtype, c1 = row sums of that, bias + W beta): dsrg_gemm_problem_t, a_stats"""
+    wf = (w.float() * gamma[None]).to(dtype)
+    return wf, wf.float().sum(1).contiguous(), (b + w.float() @ beta).contiguous()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,H,N2,act', [(2432, 768, 2304, 0), (1280, 768, 3072, 1), (130, 128, 384, 0), (65, 1024, 64, 0)])
+def test_gemm_layernorm_fusion(K, dtype, M, H, N2, act):
+    """The LayerNorm-fusion epilogue (dsrg_gemm_problem_t a_stats / r_stats / stats_out) against torch: a post-LN block
+    y = x W0^T + b0 + r, x1 = LN(y) followed by (a) a projection of x1 and (b) a dense + residual x1, with NO standalone
+    LayerNorm: launch 1 stores y and its per-tile (sum, sum of squares), launches 2 and 3 normalise on the fly.  Random
+    gamma / beta / bias; a row offset of 3 sigma so that mean != 0 is exercised."""
+    eps = 1e-12
+    x, w0, b0 = _r(M, H, dtype=dtype), _r(H, H, seed=1, scale=0.05, dtype=dtype), _r(H, seed=2)
+    r = (_r(M, H, seed=3).float() + 3.0).to(dtype)
+    gamma, beta = (1.0 + 0.3 * _r(H, seed=4)).contiguous(), 0.2 * _r(H, seed=5)
+    w1, b1 = _r(N2, H, seed=6, scale=0.05, dtype=dtype), _r(N2, seed=7)
+    w2, b2 = _r(H, N2, seed=8, scale=0.05, dtype=dtype), _r(H, seed=9)
+    np_ = H // 64
+    st = torch.zeros(M, np_, 2, device='cuda')
+    # launch 1: y (storage dtype) + partials
+    y = K.gemm([(x, w0, b0, r)], 0, False, fuse=[{'stats_out': st}])[0]
+    y_ref = x.float() @ w0.float().T + b0 + r.float()
+    tol = 2e-5 * math.sqrt(H) if dtype == torch.float32 else 3e-2
+    assert (y.float() - y_ref).abs().max().item() <= tol * max(1.0, y_ref.abs().max().item())
+    s_ref = torch.stack([y_ref.view(M, np_, 64).sum(-1), (y_ref.view(M, np_, 64) ** 2).sum(-1)], -1)
+    assert (st - s_ref).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.3) * max(1.0, s_ref.abs().max().item()) * 1e-2
+    # the reference of what follows normalises the y that was STORED (bf16: its rounding is part of the design), with the
+    # statistics of the fp32 values
+    mu, var = y_ref.mean(-1, keepdim=True), y_ref.var(-1, unbiased=False, keepdim=True)
+    x1 = (y.float() - mu) * torch.rsqrt(var + eps) * gamma + beta
+    # launch 2: act(LN(y) W1^T + b1) from the un-normalised y
+    w1f, c1, b1f = _ln_fold(w1, b1, gamma, beta, dtype)
+    h = K.gemm([(y, w1f, b1f, None)], act, False, fuse=[{'a_stats': (st, c1), 'eps': eps}])[0]
+    h_ref = ACTS[act](x1 @ w1.float().T + b1)
+    tol2 = 3e-4 if dtype == torch.float32 else 6e-2
+    assert (h.float() - h_ref).abs().max().item() <= tol2 * max(1.0, h_ref.abs().max().item()), (h.float() - h_ref).abs().max().item()
+    # launch 3: h W2^T + b2 + LN(y) as the residual, fp32 out, and partials of ITS output
+    st3 = torch.zeros(M, np_, 2, device='cuda')
+    z = K.gemm([(h, w2, b2, y)], 0, True, fuse=[{'r_stats': (st, gamma, beta), 'stats_out': st3, 'eps': eps}])[0]
+    z_ref = h.float() @ w2.float().T + b2 + x1
+    tol3 = 2e-5 * math.sqrt(N2) if dtype == torch.float32 else 1e-3 * math.sqrt(N2) / 16
+    assert (z - z_ref).abs().max().item() <= tol3 * max(1.0, z_ref.abs().max().item()), (z - z_ref).abs().max().item()
+    s3 = torch.stack([z.view(M, np_, 64).sum(-1), (z.view(M, np_, 64) ** 2).sum(-1)], -1)
+    assert (st3 - s3).abs().max().item() <= 1e-4 * max(1.0, s3.abs().max().item())
+    # and both fused features in one grouped launch next to a plain problem
+    o = K.gemm([(y, w1f, b1f, None), (x, w0, b0, None)], act, False, fuse=[{'a_stats': (st, c1), 'eps': eps}, None])
+    assert torch.equal(o[0], h) and (o[1].float() - ACTS[act](x.float() @ w0.float().T + b0)).abs().max().item() <= max(tol, 3e-2) * 10
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_gemm_grouped_strided(K, dtype):
     """two branches in one launch; strided A (row 0 of each sequence) and strided C (concat buffer)."""

@@ -53,6 +53,35 @@ def test_bf16_within_stated_tolerance(tag, reverie):
         assert (out['s%d_argmax' % t][clear] == gold['s%d_argmax' % t][clear]).all()
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fused_layernorm_path_equals_layernorm_launches(dtype):
+    """The inference path folds the x-layers' LayerNorms into GEMM epilogues (fuse_ln); with RANDOM LayerNorm gains and
+    offsets (the synthetic state dict has gamma = 1, beta = 0, which would hide a wrong fold) it must agree with the same
+    model running its standalone LayerNorm launches: fp32 to 2e-4, bf16 to the stated bf16 tolerance; same actions in fp32."""
+    gold = common.load_gold('r2r_c1')
+    m = _model('r2r_c1', False, dtype)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, p_ in m.named_parameters():
+            if 'LayerNorm' in k and ('x_layers' in k):
+                p_.copy_((1.0 + 0.3 * torch.randn(p_.shape, generator=g) if k.endswith('weight') else 0.2 * torch.randn(p_.shape, generator=g)).to(p_.device))
+    m.invalidate_caches()
+    outs = {}
+    for fuse in (True, False):
+        m.fuse_ln = fuse
+        with torch.no_grad():
+            outs[fuse] = common.run_chain(lambda mode, b: m(mode, b), gold['meta'], device='cuda')
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    for k, v in outs[True].items():
+        if k.endswith('_logits'):
+            a, b = np.asarray(v), np.asarray(outs[False][k])
+            fin = np.isfinite(b)
+            assert (np.isfinite(a) == fin).all(), k
+            assert np.abs(a[fin] - b[fin]).max() <= tol, (k, np.abs(a[fin] - b[fin]).max())
+        elif k.endswith('_argmax') and dtype == torch.float32:
+            assert (np.asarray(v) == np.asarray(outs[False][k])).all(), k
+
+
 def test_vlnbert_wrapper_and_kv_cache():
     """VLNBert(args) drop-in: defaultdict batch handling, NotImplementedError on bad mode, text-K/V cache
     gives the same result as a fresh computation, and a new txt_embeds tensor invalidates it."""
