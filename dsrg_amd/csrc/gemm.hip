@@ -53,12 +53,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // FUSE: the LayerNorm-fusion epilogue (include/dsrg_hip.h, dsrg_gemm_problem_t): built for the 64x64 tile only, launched
 // only when a problem of the group asks for it, so the plain kernels carry none of its registers.
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
+// WAVES_M x WAVES_N waves (2x2 = 256 threads for every tile but the 256x128 one, which runs 4x2 = 512 threads: two waves
+// per SIMD of 64x64 each, so that a workgroup that owns its CU still has a second wave per SIMD to issue LDS reads and
+// DMAs while the first one's MFMAs run).
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const GemmArgs args) {
   GEMM_STAMP(0);
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
-  constexpr int WM = BM / 2, WN = BN / 2;     // wave tile (2x2 waves)
+  constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;     // wave tile
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int TILE_BYTES = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r16 = lane & 15, q = lane >> 4;
 
   const T* __restrict__ A = reinterpret_cast<const T*>(P.A);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   constexpr int CW = sizeof(OutT) == 2 ? 8 : 4;     // output columns per thread = one 16-byte store (stamps: with 8-byte
                                                     // bf16 stores the epilogue was store-issue-bound, ~7 B/clk per CU)
   constexpr int CPR = BN / CW;                      // threads per image row
-  constexpr int RPP = 256 / CPR;                    // rows per pass (threads past RPP*CPR idle when 256 % CPR != 0)
+  constexpr int RPP = THREADS / CPR;                // rows per pass (threads past RPP*CPR idle when THREADS % CPR != 0)
   const int oc = tid % CPR, orow0 = tid / CPR;
   const int n = n0 + oc * CW;
   const bool vec = (n + CW - 1 < N) && (P.ldc % CW == 0) && (Rp == nullptr || (P.ldr % CW == 0 && ((uintptr_t)Rp & 15) == 0));
@@ -175,12 +179,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   // Addresses are scalar base (A or W, advanced along K in SGPRs) + a per-lane 32-bit byte offset that never changes,
   // so one DMA costs three scalar instructions and no vector ALU work.
   constexpr int TR = BM + BN;           // tile rows per stage (A rows then W rows)
-  constexpr int LPS = TR / 32;          // LDS-DMA instructions per wave per stage
-  constexpr int LPA = BM / 32;          // ... of which the first LPA fetch A rows
+  constexpr int LPS = TR / (8 * NWAVES);   // LDS-DMA instructions per wave per stage
+  constexpr int LPA = BM / (8 * NWAVES);   // ... of which the first LPA fetch A rows
+  static_assert(TR % (8 * NWAVES) == 0 && BM % (8 * NWAVES) == 0, "a DMA piece is 8 rows per wave");
   unsigned voff[LPS];
 #pragma unroll
   for (int i = 0; i < LPS; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);  // row of the stage
+    const int row = (i * NWAVES + wave) * 8 + (lane >> 3);  // row of the stage
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (i < LPA) voff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(P.lda * (int)sizeof(T)) + chunk * 16;
     else voff[i] = (unsigned)min(n0 + row - BM, N - 1) * (unsigned)(P.ldw * (int)sizeof(T)) + chunk * 16;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   // tracked by the counted s_waitcnt below.  M0 (LDS destination base) is written in the statement that uses it.
   const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
   auto issue1 = [&](int i, int stage, int k0) {
-    const unsigned dst = ldsw + stage * TILE_BYTES + i * 4096;
+    const unsigned dst = ldsw + stage * TILE_BYTES + i * (NWAVES * 1024);
     const T* base = (i < LPA ? A : W) + k0;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
   // Tiles whose fp32 image does not fit the ring (256x192: 192 KiB) leave in two passes, one per wave row.
   constexpr int EPASS = (BM * BN * 4 > NST * TILE_BYTES) ? 2 : 1;
   constexpr int EROWS = BM / EPASS;
-  static_assert(EPASS == 1 || EROWS == WM, "two-pass epilogue splits the tile by wave row");
+  static_assert(EPASS == 1 || EROWS % WM == 0, "two-pass epilogue splits the tile between wave rows");
   static_assert(EPASS == 1 || EROWS * BN * 4 <= NST * TILE_BYTES, "a half image must fit the ring");
   float* cimg = reinterpret_cast<float*>(smem);
   // The residual pieces of this thread's rows are fetched NOW, ahead of the two barriers and the image round trip
@@ -370,10 +375,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
       lnpart[(0 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sa;
       lnpart[(1 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sr2;
     }
-    if (EPASS == 1 || wm == ep) {
+    if (EPASS == 1 || (wm * WM) / EROWS == ep) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int row = (EPASS == 1 ? wm * WM : 0) + i * 16 + r16;
+        const int row = wm * WM - (EPASS == 1 ? 0 : ep * EROWS) + i * 16 + r16;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int chunk = (wn * WN + j * 16) / 4 + q;
@@ -473,13 +478,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs args) {
 #endif
 }
 
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false>
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
   constexpr int smem_main = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
   constexpr int smem = smem_main;
-  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE>), smem);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE>), dim3(total_tiles), dim3(256), smem, s, a);
+  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N>), smem);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N>), dim3(total_tiles), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
   return DSRG_OK;
 }
@@ -502,7 +507,7 @@ struct TileShape { int bm, bn, nst[4]; bool f32_ok; };
 constexpr TileShape kTiles[] = {
   {64, 64, {2, 3, 4, 0}, true},   {64, 128, {2, 3, 0, 0}, true},  {64, 192, {3, 0, 0, 0}, false}, {64, 256, {3, 0, 0, 0}, false},
   {128, 64, {3, 2, 4, 0}, false}, {128, 96, {3, 0, 0, 0}, false}, {128, 128, {2, 3, 0, 0}, true}, {128, 192, {3, 2, 0, 0}, false},
-  {128, 256, {3, 0, 0, 0}, false},
+  {128, 256, {3, 0, 0, 0}, false}, {256, 128, {3, 2, 0, 0}, false},      // 256x128: 8 waves (4x2)
 };
 const TileShape* find_tile(int bm, int bn, bool bf16) {
   for (const TileShape& t : kTiles)
@@ -536,8 +541,11 @@ int count_tiles(GemmArgs& a, int m, int n) {
 //    branch, object / view encoder), and what counts is how many workgroups of BOTH kernels a CU holds.  A/B of the whole
 //    step on one box (bench.py, ms per step): round 1's plan 1.233 | per-launch-best tiles and depths 1.255 | 64x64 with a
 //    3-deep ring everywhere 1.201 | 64x128x2 everywhere 1.356 | 128x64x3 1.253 | 128x128x2 1.535.  So: 64x64, 3-deep ring
-//    (48 KiB: three workgroups per CU), 2-deep from 1024 tiles on (4+ rounds: occupancy hides the latency), and 128x128
-//    only for the big once-per-episode GEMMs (text K/V panel, >= 1000 tiles of 128x128: 164 -> 128 us).
+//    (48 KiB: three workgroups per CU), 2-deep from 1024 tiles on (4+ rounds: occupancy hides the latency), and the
+//    8-wave 256x128 tile (one workgroup per CU, two 64x64 waves per SIMD) only for the big once-per-episode GEMMs (text
+//    K/V panel, >= 1000 tiles of 128x128: 158 -> 124 us; 4096^3: 190 -> 111 us = 1.24 PFLOP/s).  The same tile on the
+//    panorama FFN-in (2 launches per step, 24.6 -> 22.6 us each on their own) makes the STEP 20 us slower: it takes the
+//    whole CU's LDS while the object-token encoder's launches on the other stream wait.
 int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int fbn, int fnst) {
   nst = 0;
   if (fbm <= 0) {
@@ -559,8 +567,9 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
   }
   bool fuse = false;
   for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
-  if (!fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) { bm = 128; bn = 128; nst = 2; }
-  else {
+  if (!fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) {
+    if (bf16) { bm = 256; bn = 128; nst = 3; } else { bm = 128; bn = 128; nst = 2; }
+  } else {
     bm = 64; bn = 64;
     nst = count_tiles(a, 64, 64) > 1024 ? 2 : 3;
   }
@@ -609,6 +618,8 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
     DSRG_TILE_CASE(128, 96, 3);
     DSRG_TILE_CASE(128, 192, 2); DSRG_TILE_CASE(128, 192, 3);
     DSRG_TILE_CASE(128, 256, 3);
+    if (bm == 256 && bn == 128 && nst == 3) return launch<T, OutT, 256, 128, 3, false, 4, 2>(a, tiles, s);
+    if (bm == 256 && bn == 128 && nst == 2) return launch<T, OutT, 256, 128, 2, false, 4, 2>(a, tiles, s);
   }
 #undef DSRG_TILE_CASE
   DSRG_CHECK(false, "dsrg_gemm_nt: no kernel for tile %dx%d ring %d", bm, bn, nst);

@@ -43,7 +43,7 @@ SHAPES = [  # name, [(M,N,K)...] grouped, act, out_f32, residual
 ]
 
 TILES = [(64, 64, 2), (64, 64, 3), (64, 64, 4), (64, 128, 2), (64, 128, 3), (64, 192, 3), (64, 256, 3), (128, 64, 2), (128, 64, 3), (128, 64, 4),
-         (128, 96, 3), (128, 128, 2), (128, 128, 3), (128, 192, 2), (128, 192, 3), (128, 256, 3)]
+         (128, 96, 3), (128, 128, 2), (128, 128, 3), (128, 192, 2), (128, 192, 3), (128, 256, 3), (256, 128, 2), (256, 128, 3)]
 
 
 def time_graph(fn, inner=20, rep=5):
