@@ -623,6 +623,330 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 attention backward on the matrix cores (the fp32 kernels above stay the exact-fp32 parity path and the fallback
+// for operands that are not 16-byte aligned).  Same two-launch split and the same recompute from the forward's
+// log-sum-exp; both kernels reuse the forward kernel's operand tricks:
+//   * a score tile leaves the MFMA with one operand's row index in the lane (c = lane & 15) and the other's in the
+//     register index (4g + r), so per-lane scalars (lse / delta of the lane's query, or the mask term of the lane's key)
+//     apply to all of a lane's accumulators;
+//   * the element-wise result (dS, or P) goes STRAIGHT from those accumulators into the B operand of the next MFMA whose
+//     contraction runs over the register index; the other operand is read from a transposed LDS image with the matching
+//     k-slot permutation (two ds_read_b64 32 bytes apart), as the forward does for P.V.
+// attention_bwd_mfma_dq : grid (ceil(Nq/64), NH, B), wave <-> 16 queries, keys in chunks of 128:
+//     S^T = K Q^T, dP^T = V dO^T (accumulators: rows = keys, lane = query), dS^T -> B operand of dQ^T += K^T dS^T.
+// attention_bwd_mfma_dkv: grid (ceil(Nk/64), NH, B), wave <-> 16 keys, queries in chunks of 128:
+//     S = Q K^T, dP = dO V^T (rows = queries, lane = key), P and dS -> B operands of dV^T += dO^T P, dK^T += Q^T dS.
+struct RowRegs { uint4 r[4]; };
+
+// 128 rows x 64 columns of one head, row-major: thread (r = tid >> 3, c = tid & 7) holds rows r + 32p, 16-byte chunk c
+__device__ __forceinline__ void ld_rows(RowRegs& L, const bf16_t* P, int rs, int r0, int nr, int tid) {
+  const int r = tid >> 3, c = tid & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) L.r[p] = *reinterpret_cast<const uint4*>(P + (size_t)(r0 + min(r + 32 * p, nr - 1)) * rs + c * 8);
+}
+__device__ __forceinline__ void st_rows(char* S, const RowRegs& L, int nr, int ntile, int tid) {
+  const int r = tid >> 3, c = tid & 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = r + 32 * p;
+    if (row < ntile * 16) *reinterpret_cast<uint4*>(S + kswz(row, c)) = row < nr ? L.r[p] : make_uint4(0, 0, 0, 0);
+  }
+}
+// the same rows for the transposed image T[d][row] (VRS-byte rows): thread (row = tid & 127, dc0 = tid >> 7) holds chunks dc0 + 2p
+__device__ __forceinline__ void ld_cols(RowRegs& L, const bf16_t* P, int rs, int r0, int nr, int tid) {
+  const int row = tid & 127, dc0 = tid >> 7;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) L.r[p] = *reinterpret_cast<const uint4*>(P + (size_t)(r0 + min(row, nr - 1)) * rs + (dc0 + 2 * p) * 8);
+}
+__device__ __forceinline__ void st_cols(char* St, const RowRegs& L, int nr, int ntile, int tid) {
+  const int row = tid & 127, dc0 = tid >> 7;
+  if (row < ntile * 16) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int dc = dc0 + 2 * p;
+      const uint4 v = row < nr ? L.r[p] : make_uint4(0, 0, 0, 0);
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(St + (dc * 8 + j) * VRS + row * 2) = e[j];
+    }
+  }
+}
+__device__ __forceinline__ float dot8(const uint4& x, const uint4& y) {
+  const float4 a0 = raw4(make_uint2(x.x, x.y)), a1 = raw4(make_uint2(x.z, x.w)), b0 = raw4(make_uint2(y.x, y.y)), b1 = raw4(make_uint2(y.z, y.w));
+  return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+}
+// fragment of a transposed image for the MFMA whose B operand comes from a pair (2j, 2j+1) of score tiles
+__device__ __forceinline__ bf16x8 tfrag(const char* St, int dt, int c16, int j, int g) {
+  const char* vp = St + (dt * 16 + c16) * VRS + (32 * j + 4 * g) * 2;
+  const uint2 v0 = *reinterpret_cast<const uint2*>(vp), v1 = *reinterpret_cast<const uint2*>(vp + 32);
+  return __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBwdArgs ba) {
+  const AttnArgs& a = ba.f;
+  __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[KC * 128];
+  __shared__ __attribute__((aligned(16))) char Kt[DH * VRS];
+  __shared__ float mt[KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const bool active = q0 < a.Nq;                               // wave-uniform
+  const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
+  const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + b * a.v_bs + h * DH;
+  const bf16_t* Op = reinterpret_cast<const bf16_t*>(a.O) + b * a.o_bs + h * DH;
+  const bf16_t* Gp = reinterpret_cast<const bf16_t*>(ba.dO) + b * ba.do_bs + h * DH;
+  const int qrow = q0 + c16, qc = min(qrow, a.Nq - 1);
+  const bool qok = active && qrow < a.Nq;
+  // this lane's query row: Q, dO, O (16 of its 64 columns each), log-sum-exp; delta = dO . O over the 4 lanes of the row
+  uint4 qf[2], gf[2], of[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    qf[kk] = *reinterpret_cast<const uint4*>(Qp + (size_t)qc * a.q_rs + 32 * kk + g * 8);
+    gf[kk] = *reinterpret_cast<const uint4*>(Gp + (size_t)qc * ba.do_rs + 32 * kk + g * 8);
+    of[kk] = *reinterpret_cast<const uint4*>(Op + (size_t)qc * a.o_rs + 32 * kk + g * 8);
+  }
+  const size_t srow = ((size_t)b * a.NH + h) * a.Nq + qc;
+  const float lse_q = a.lse[srow];
+  float delta = dot8(gf[0], of[0]) + dot8(gf[1], of[1]);
+  delta += __shfl_xor(delta, 16);
+  delta += __shfl_xor(delta, 32);
+  if (qok && g == 0) ba.delta[srow] = delta;
+  if (!qok) { qf[0] = qf[1] = gf[0] = gf[1] = make_uint4(0, 0, 0, 0); }
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+  const float* drow = a.dists ? a.dists + ((size_t)b * a.Nq + qc) * a.Nk : nullptr;
+  f32x4 dq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float gsw = 0.f, gsb = 0.f;
+
+  for (int k0 = 0; k0 < a.Nk; k0 += KC) {
+    const int nk = min(KC, a.Nk - k0);
+    const int ntile = ((nk + 31) / 32) * 2;
+    {
+      RowRegs kr, vr, kc;
+      ld_rows(kr, Kp, a.k_rs, k0, nk, tid);
+      ld_rows(vr, Vp, a.v_rs, k0, nk, tid);
+      ld_cols(kc, Kp, a.k_rs, k0, nk, tid);
+      uint8_t mkb = 1;
+      if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + k0 + min(tid & (KC - 1), nk - 1)];
+      if (k0) __syncthreads();                                 // every wave is done with the previous chunk
+      st_rows(Ks, kr, nk, ntile, tid);
+      st_rows(Vs, vr, nk, ntile, tid);
+      st_cols(Kt, kc, nk, ntile, tid);
+      if (tid < KC) {
+        float t = -INFINITY;
+        if (tid < nk) {
+          t = 0.f;
+          if (a.kmask) {
+            const bool mk = mkb != 0;
+            if (a.mask_mode == DSRG_MASK_NEG10000) t = mk ? 0.f : -10000.0f;
+            else if (a.mask_mode == DSRG_MASK_NEGINF) t = mk ? 0.f : -INFINITY;
+            else if (a.mask_mode == DSRG_MASK_PLUS1) t = mk ? 1.0f : 0.f;
+          }
+        }
+        mt[tid] = t;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    auto compute = [&](auto nt_tag) {
+      constexpr int NTL = decltype(nt_tag)::value;
+      f32x4 s[NTL], dp[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kswz(t * 16 + c16, g + 4 * kk));
+          const uint4 vf = *reinterpret_cast<const uint4*>(Vs + kswz(t * 16 + c16, g + 4 * kk));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[kk]), s[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, gf[kk]), dp[t], 0, 0, 0);
+        }
+      }
+      const float ik = DROP ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+      const size_t rbase = (((size_t)b * a.NH + h) * a.Nq + qc) * a.Nk + k0;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const float4 mk = *reinterpret_cast<const float4*>(&mt[t * 16 + 4 * g]);
+        const float mm[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = t * 16 + 4 * g + r;
+          float v = s[t][r] * a.scale + mm[r], dist = 0.f;
+          if (drow && kl < nk) { dist = drow[k0 + kl]; v += dist * sw + sb; }
+          const float pr = __expf(v - lse_q);                  // 0 for padded / -inf-masked keys
+          float d = dp[t][r];
+          if (DROP && kl < nk) d *= drop_keep(a.seed, rbase + kl, a.p_drop, ik);
+          const float ds = qok ? pr * (d - delta) : 0.f;
+          gsw += ds * dist; gsb += ds;
+          s[t][r] = ds;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NTL / 2; ++j) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, dt, c16, j, g), pf, dq[dt], 0, 0, 0);
+      }
+    };
+    switch (ntile) {
+      case 2: compute(std::integral_constant<int, 2>{}); break;
+      case 4: compute(std::integral_constant<int, 4>{}); break;
+      case 6: compute(std::integral_constant<int, 6>{}); break;
+      default: compute(std::integral_constant<int, 8>{}); break;
+    }
+  }
+  if (qok) {
+    bf16_t* dQp = reinterpret_cast<bf16_t*>(ba.dQ) + ((size_t)b * a.Nq + qrow) * (a.NH * DH) + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      st4(dQp + dt * 16 + 4 * g, make_float4(dq[dt][0] * a.scale, dq[dt][1] * a.scale, dq[dt][2] * a.scale, dq[dt][3] * a.scale));
+  }
+  if (ba.dsprel && a.dists) {
+    gsw = wave_sum(gsw); gsb = wave_sum(gsb);
+    if (lane == 0 && active) { atomicAdd(ba.dsprel, gsw); atomicAdd(ba.dsprel + 1, gsb); }
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnBwdArgs ba) {
+  const AttnArgs& a = ba.f;
+  __shared__ __attribute__((aligned(16))) char Qs[KC * 128];
+  __shared__ __attribute__((aligned(16))) char Gs[KC * 128];
+  __shared__ __attribute__((aligned(16))) char Qt[DH * VRS];
+  __shared__ __attribute__((aligned(16))) char Gt[DH * VRS];
+  __shared__ __attribute__((aligned(16))) float Ls[KC];
+  __shared__ __attribute__((aligned(16))) float Dl[KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kb = (blockIdx.x * 4 + wave) * 16;
+  const bool active = kb < a.Nk;                               // wave-uniform
+  const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
+  const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + b * a.v_bs + h * DH;
+  const bf16_t* Gp = reinterpret_cast<const bf16_t*>(ba.dO) + b * ba.do_bs + h * DH;
+  const int key = kb + c16, kc_ = min(key, a.Nk - 1);
+  // this lane's key row of K and V; its mask term (-inf: key beyond Nk or masked with -inf -> P = 0)
+  uint4 kf[2], vf[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    kf[kk] = *reinterpret_cast<const uint4*>(Kp + (size_t)kc_ * a.k_rs + 32 * kk + g * 8);
+    vf[kk] = *reinterpret_cast<const uint4*>(Vp + (size_t)kc_ * a.v_rs + 32 * kk + g * 8);
+  }
+  float mterm = 0.f;
+  {
+    uint8_t mkb = 1;
+    if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + kc_];
+    if (a.kmask) {
+      const bool mk = mkb != 0;
+      if (a.mask_mode == DSRG_MASK_NEG10000) mterm = mk ? 0.f : -10000.0f;
+      else if (a.mask_mode == DSRG_MASK_NEGINF) mterm = mk ? 0.f : -INFINITY;
+      else if (a.mask_mode == DSRG_MASK_PLUS1) mterm = mk ? 1.0f : 0.f;
+    }
+    if (!active || key >= a.Nk) mterm = -INFINITY;
+  }
+  const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < a.Nq; q0 += KC) {
+    const int nq = min(KC, a.Nq - q0);
+    const int ntile = ((nq + 31) / 32) * 2;
+    {
+      RowRegs qr, gr, qcol, gcol;
+      ld_rows(qr, Qp, a.q_rs, q0, nq, tid);
+      ld_rows(gr, Gp, ba.do_rs, q0, nq, tid);
+      ld_cols(qcol, Qp, a.q_rs, q0, nq, tid);
+      ld_cols(gcol, Gp, ba.do_rs, q0, nq, tid);
+      const size_t li = ((size_t)b * a.NH + h) * a.Nq + q0 + min(tid & (KC - 1), nq - 1);
+      const float lv = a.lse[li], dl = ba.delta[li];
+      if (q0) __syncthreads();                                 // every wave is done with the previous chunk
+      st_rows(Qs, qr, nq, ntile, tid);
+      st_rows(Gs, gr, nq, ntile, tid);
+      st_cols(Qt, qcol, nq, ntile, tid);
+      st_cols(Gt, gcol, nq, ntile, tid);
+      if (tid < KC) {
+        Ls[tid] = tid < nq ? lv : INFINITY;                    // exp(s - inf) = 0 for the padding rows
+        Dl[tid] = tid < nq ? dl : 0.f;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    auto compute = [&](auto nt_tag) {
+      constexpr int NTL = decltype(nt_tag)::value;
+      f32x4 s[NTL], dp[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const uint4 qv = *reinterpret_cast<const uint4*>(Qs + kswz(t * 16 + c16, g + 4 * kk));
+          const uint4 gv = *reinterpret_cast<const uint4*>(Gs + kswz(t * 16 + c16, g + 4 * kk));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qv), __builtin_bit_cast(bf16x8, kf[kk]), s[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gv), __builtin_bit_cast(bf16x8, vf[kk]), dp[t], 0, 0, 0);
+        }
+      }
+      const float ik = DROP ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const float4 l4 = *reinterpret_cast<const float4*>(&Ls[t * 16 + 4 * g]), d4 = *reinterpret_cast<const float4*>(&Dl[t * 16 + 4 * g]);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = t * 16 + 4 * g + r, qg = q0 + ql;
+          float v = s[t][r] * a.scale + mterm;
+          if (a.dists && ql < nq && key < a.Nk) v += a.dists[((size_t)b * a.Nq + qg) * a.Nk + key] * sw + sb;
+          const float pr = __expf(v - ll[r]);
+          float keep = 1.f;
+          if (DROP && ql < nq && key < a.Nk) keep = drop_keep(a.seed, (((size_t)b * a.NH + h) * a.Nq + qg) * a.Nk + key, a.p_drop, ik);
+          const float d = dp[t][r] * keep;
+          s[t][r] = pr * keep;                                 // what multiplied V in the forward
+          dp[t][r] = pr * (d - dd[r]) * a.scale;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NTL / 2; ++j) {
+        bf16x8 pf, df;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r];
+          df[r] = (__bf16)dp[2 * j][r]; df[4 + r] = (__bf16)dp[2 * j + 1][r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, dt, c16, j, g), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, dt, c16, j, g), df, dk[dt], 0, 0, 0);
+        }
+      }
+    };
+    switch (ntile) {
+      case 2: compute(std::integral_constant<int, 2>{}); break;
+      case 4: compute(std::integral_constant<int, 4>{}); break;
+      case 6: compute(std::integral_constant<int, 6>{}); break;
+      default: compute(std::integral_constant<int, 8>{}); break;
+    }
+  }
+  if (active && key < a.Nk) {
+    bf16_t* dKp = reinterpret_cast<bf16_t*>(ba.dK) + ((size_t)b * a.Nk + key) * (a.NH * DH) + h * DH;
+    bf16_t* dVp = reinterpret_cast<bf16_t*>(ba.dV) + ((size_t)b * a.Nk + key) * (a.NH * DH) + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      st4(dKp + dt * 16 + 4 * g, make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]));
+      st4(dVp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef DSRG_ATTN_STAMPS
@@ -718,6 +1042,22 @@ static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void*
                  dO, do_bs, do_rs, dQ, dK, dV, delta_ws, dsprel};
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((Nq + QPB - 1) / QPB, NH, B), gk((Nk + KT - 1) / KT, NH, B), block(256);
+  // bf16 with 16-byte addressable rows: the matrix-core kernels (64 queries / 64 keys per workgroup)
+  const bool mfma_ok = dtype == DSRG_BF16 && q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && do_rs % 8 == 0 && q_bs % 8 == 0 &&
+                       k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0 && do_bs % 8 == 0 &&
+                       (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) == 0;
+  if (mfma_ok) {
+    dim3 mq((Nq + 63) / 64, NH, B), mk((Nk + 63) / 64, NH, B);
+    if (p_drop > 0.f) {
+      hipLaunchKernelGGL((attention_bwd_mfma_dq_kernel<true>), mq, block, 0, s, ba);
+      hipLaunchKernelGGL((attention_bwd_mfma_dkv_kernel<true>), mk, block, 0, s, ba);
+    } else {
+      hipLaunchKernelGGL((attention_bwd_mfma_dq_kernel<false>), mq, block, 0, s, ba);
+      hipLaunchKernelGGL((attention_bwd_mfma_dkv_kernel<false>), mk, block, 0, s, ba);
+    }
+    DSRG_LAUNCH_CHECK("dsrg_attention_bwd");
+    return DSRG_OK;
+  }
   if (dtype == DSRG_F32) {
     hipLaunchKernelGGL((attention_bwd_dq_kernel<float>), gq, block, 0, s, ba);
     hipLaunchKernelGGL((attention_bwd_dkv_kernel<float>), gk, block, 0, s, ba);
