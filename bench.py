@@ -242,6 +242,7 @@ def pretrain_main(a, dtype, dev, rank, world):
                             lr=5e-5, betas=(0.9, 0.98), fused=True)
     batches = {t: T(synth.pretrain_batch(PT_B, PT_L, 3, 200 + rank, t, min_steps=4, max_steps=7), dev) for t in PT_TASKS}
     last = {}
+    params = [p for p in model.parameters() if p.requires_grad]      # walking the module tree costs ~1.4 ms of host time per step
 
     def step(i):
         task = PT_TASKS[i % len(PT_TASKS)]
@@ -250,7 +251,7 @@ def pretrain_main(a, dtype, dev, rank, world):
         opt.zero_grad(set_to_none=True)
         loss = ddp(batches[task], task, compute_loss=True).mean()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
         last[task] = loss.detach()
 

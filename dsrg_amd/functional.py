@@ -147,7 +147,7 @@ def _gemm_grads(items):
     group of dgrad / wgrad GEMMs is ONE grouped launch of the forward NT kernel on transposed operands; the bias
     gradients (column sums of dy) are taken by the kernel that transposes dy, into one zeroed buffer."""
     nb = sum(it[1].shape[0] for it in items if it[5])
-    dball = torch.zeros(nb, device=items[0][2].device, dtype=torch.float32) if nb else None
+    dball = K.zeros_f32((nb,), items[0][2].device) if nb else None
     dxp, dwp, dbs, o = [], [], [], 0
     tr = []                                    # every transpose of this call: one grouped launch
     for x, w, dy, ndx, ndw, ndb in items:

@@ -33,6 +33,31 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_ZERO_POOL = {}
+_ZERO_POOL_ON = __import__('os').environ.get('DSRG_ZERO_POOL', '1') == '1'
+_ZERO_CHUNK = 1 << 20          # fp32 elements per chunk (4 MiB)
+
+
+def zeros_f32(shape, device):
+    """Small zero-initialised fp32 accumulator (column sums, LayerNorm / bias gradients, sprel gradients ...).  A training
+    step needs ~300 of them; each torch.zeros is a fill launch plus ~8 us of host time, so they are carved out of 4 MiB
+    chunks that ONE fill zeroes (a chunk is handed out once and never reused: slices may live on as .grad).  Under HIP-graph
+    capture, or for large requests, this is torch.zeros."""
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= int(d)
+    if n > 65536 or not _ZERO_POOL_ON or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _raw_stream(torch.cuda.current_device()) if _raw_stream else 0)
+    st = _ZERO_POOL.get(key)
+    na = (n + 63) // 64 * 64
+    if st is None or st[1] + na > _ZERO_CHUNK:
+        st = _ZERO_POOL[key] = [torch.zeros(_ZERO_CHUNK, device=device, dtype=torch.float32), 0]
+    out = st[0][st[1]:st[1] + n].view(shape)
+    st[1] += na
+    return out
+
+
 def rows_ok(t):
     """t as-is if its leading dims collapse onto one row stride (what every row kernel needs), else a contiguous copy:
     incoming gradients can be arbitrary views (e.g. the slice of a longer token sequence)."""
@@ -54,7 +79,10 @@ def _dev(t):
 def _rows(t):
     """[..., H] tensor -> (M, ld) treating it as rows; requires unit stride on the last dim and
     uniform row stride."""
-    if t.dim() == 1:
+    nd = t.dim()
+    if nd == 2 and t.stride(1) == 1:             # the common case on the training path (one call per operand per launch)
+        return t.shape[0], t.stride(0)
+    if nd == 1:
         return 1, t.shape[0]
     if t.is_contiguous():
         H = t.shape[-1]
@@ -236,7 +264,7 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     dk = torch.empty(B, Nk, nh * 64, device=q.device, dtype=q.dtype)
     dv = torch.empty_like(dk)
     delta = torch.empty(B, nh, Nq, device=q.device, dtype=torch.float32)
-    dsp = torch.zeros(2, device=q.device, dtype=torch.float32) if dists is not None else None
+    dsp = zeros_f32((2,), q.device) if dists is not None else None
     bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
     _lib.check(lib.dsrg_attention_bwd(
         _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
@@ -471,7 +499,7 @@ def colsum(x):
     lib = _lib.load()
     _dev(x)
     M, N = x.shape
-    out = torch.zeros(N, device=x.device, dtype=torch.float32)
+    out = zeros_f32((N,), x.device)
     _lib.check(lib.dsrg_colsum_acc(_p(x), x.stride(0), _p(out), M, N, _dt(x), _stream()), 'dsrg_colsum_acc')
     return out
 
@@ -501,7 +529,7 @@ def layernorm_bwd(x, residual, gamma, dy, eps):
     H = x.shape[-1]
     dy = rows_ok(dy)
     dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
-    dgb = torch.zeros(2, H, device=x.device, dtype=torch.float32)
+    dgb = zeros_f32((2, H), x.device)
     dg, db = dgb[0], dgb[1]
     ldr = _rows(residual)[1] if residual is not None else 0
     _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
@@ -551,7 +579,7 @@ def gaa_pool_bwd(x, w, b, dout):
     B, V, H = x.shape
     dout = dout.to(x.dtype).contiguous()
     dx = torch.empty_like(x)
-    dwb = torch.zeros(H + 1, device=x.device, dtype=torch.float32)
+    dwb = zeros_f32((H + 1,), x.device)
     _lib.check(lib.dsrg_gaa_pool_bwd(_p(x), _p(w), _p(b), _p(dout), _p(dx), _p(dwb), dwb.data_ptr() + 4 * H, B, V, H, _dt(x), _stream()),
                'dsrg_gaa_pool_bwd')
     return dx, dwb[:H], dwb[H:]
@@ -563,7 +591,7 @@ def head_tail_bwd(h, gamma, beta, w2, dscore, eps=1e-12):
     H = h.shape[-1]
     dscore = dscore.float().contiguous()
     dh = torch.empty(h.shape, device=h.device, dtype=torch.float32)
-    acc = torch.zeros(3 * H + 1, device=h.device, dtype=torch.float32)
+    acc = zeros_f32((3 * H + 1,), h.device)
     base = acc.data_ptr()
     _lib.check(lib.dsrg_head_tail_bwd(_p(h), ldh, _p(gamma), _p(beta), _p(w2), _p(dscore), float(eps), _p(dh), H, base, base + 4 * H,
                                       base + 8 * H, base + 12 * H, M, H, _stream()), 'dsrg_head_tail_bwd')
@@ -590,7 +618,7 @@ def igl_blend_bwd(aug, x, wa, ba, wo, bo, dout):
     M = x.numel() // H
     dout = dout.to(x.dtype).contiguous()
     daug, dx = torch.empty_like(aug), torch.empty_like(x)
-    acc = torch.zeros(2 * H + 2, device=x.device, dtype=torch.float32)
+    acc = zeros_f32((2 * H + 2,), x.device)
     base = acc.data_ptr()
     _lib.check(lib.dsrg_igl_blend_bwd(_p(aug), _p(x), _p(wa), _p(ba), _p(wo), _p(bo), _p(dout), _p(daug), _p(dx), base, base + 4 * H,
                                       base + 8 * H, M, H, _dt(x), _stream()), 'dsrg_igl_blend_bwd')
@@ -610,7 +638,7 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
     lno_g, lno_b = lno if lno is not None else (None, None)
     i1, k1, s1, d1 = _idx(idx1 if E1 is not None else None, M, 'idx1')
     i2, k2, s2, d2 = _idx(idx2 if E2 is not None else None, M, 'idx2')
-    z = lambda t: None if t is None else torch.zeros_like(t, dtype=torch.float32)
+    z = lambda t: None if t is None else zeros_f32(tuple(t.shape), dev)
     g = {'Wf': z(Wf) if feat is not None else None, 'bf': z(bf) if feat is not None else None,
          'lnf_g': z(lnf_g), 'lnf_b': z(lnf_b), 'E1': z(E1), 'E2': z(E2), 'vec': z(vec), 'lno_g': z(lno_g), 'lno_b': z(lno_b),
          'base': torch.empty(M, H, device=dev, dtype=dout.dtype) if (base is not None and need_dbase) else None}
