@@ -109,14 +109,16 @@ def cpu_baseline(cfg, sd, lb, pb, nb, dims, budget_s=20.0):
                       % (it, B, torch.__version__, cores, dt)}
 
 
-def pmc_traffic(kernel_sig, grids):
+def pmc_traffic(kernel_sig, grids, cfg='c2'):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_fetch.csv,
     *_pmc_write.csv; separate --pmc runs of this same bench, summarised by tools/pmc_summary.py).  FETCH_SIZE and
     WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled (MI355X_MICROARCH.md,
     HBM section).  Averaged over the launches of one step, matched by kernel template + grid size.  None if absent."""
     import csv, glob
     here = os.path.dirname(os.path.abspath(__file__))
-    fetch, write = sorted(glob.glob(os.path.join(here, 'profiles', '*_pmc_fetch.csv'))), sorted(glob.glob(os.path.join(here, 'profiles', '*_pmc_write.csv')))
+    tag = '' if cfg == 'c2' else cfg + '_'          # profiles/rNN_pmc_fetch.csv (c2) / rNN_c4_pmc_fetch.csv (pre-training step)
+    fetch = sorted(f for f in glob.glob(os.path.join(here, 'profiles', 'r*_%spmc_fetch.csv' % tag)) if cfg != 'c2' or '_c4_' not in f)
+    write = sorted(f for f in glob.glob(os.path.join(here, 'profiles', 'r*_%spmc_write.csv' % tag)) if cfg != 'c2' or '_c4_' not in f)
     if not fetch or not write:
         return None, None
 
@@ -135,12 +137,12 @@ def pmc_traffic(kernel_sig, grids):
     return tot / len(grids), os.path.basename(fetch[-1])
 
 
-def profile_avg_us(kernel_sig):
+def profile_avg_us(kernel_sig, cfg='c2'):
     """Average in-step duration (us) of a kernel variant from the newest committed `rocprofv3 --kernel-trace --stats`
     summary of this bench (profiles/*_bench_c2_kernel_stats.csv: Name, Calls, TotalDurationNs, AverageNs ...), or None."""
     import csv, glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_bench_c2_kernel_stats.csv')))
+    files = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_bench_%s_kernel_stats.csv' % cfg)))
     if not files:
         return None, None
     for r in csv.DictReader(open(files[-1])):
@@ -149,7 +151,7 @@ def profile_avg_us(kernel_sig):
     return None, os.path.basename(files[-1])
 
 
-def gemm_roofline(step_fn, dtype):
+def gemm_roofline(step_fn, dtype, cfg='c2'):
     """Dominant kernel = the grouped NT GEMM.  Record every dsrg_gemm_nt launch of ONE eager nav-step and time, per
     kernel variant (tile, ring depth, output type), its launches as they run inside a step: all launches of the variant,
     in step order, each on its own operands (so A / W / residual come from beyond the XCD L2s, as in the step), captured
@@ -201,8 +203,8 @@ def gemm_roofline(step_fn, dtype):
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
     sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d, %s,' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
                                                        'float' if odt == 0 else 'unsigned short', bm, bn, nst, 'true' if fused else 'false')
-    traffic, src = pmc_traffic(sig, d['grids'])
-    prof_us, prof_src = profile_avg_us(sig)
+    traffic, src = pmc_traffic(sig, d['grids'], cfg)
+    prof_us, prof_src = profile_avg_us(sig, cfg)
     fpl = d['flops'] / d['launches']
     return {'bound': 'mfma', 'achieved': d['flops'] / d['time'] / 1e12, 'peak': peak / 1e12, 'unit': 'TFLOP/s',
             'frac': d['flops'] / d['time'] / peak, 'frac_isolated': d['flops'] / d['hot'] / peak,
@@ -248,9 +250,15 @@ def pretrain_main(a, dtype, dev, rank, world):
         task = PT_TASKS[i % len(PT_TASKS)]
         if world > 1:
             task = PT_TASKS[D.broadcast_task_id(PT_TASKS.index(task), dev)]
+        dbg = os.environ.get('DSRG_BENCH_HANG_DUMP')
+        t_ = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss = ddp(batches[task], task, compute_loss=True).mean()
+        if dbg:
+            torch.cuda.synchronize(); print('rank %d step %d %s forward %.2f s' % (rank, i, task, time.perf_counter() - t_), file=sys.stderr, flush=True)
         loss.backward()
+        if dbg:
+            torch.cuda.synchronize(); print('rank %d step %d backward done %.2f s' % (rank, i, time.perf_counter() - t_), file=sys.stderr, flush=True)
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
         last[task] = loss.detach()
@@ -288,7 +296,7 @@ def pretrain_main(a, dtype, dev, rank, world):
             def one_step():
                 opt.zero_grad(set_to_none=True)
                 model(batches['sap'], 'sap', compute_loss=True).mean().backward()
-            out['roofline'] = gemm_roofline(one_step, dtype)
+            out['roofline'] = gemm_roofline(one_step, dtype, 'c4')
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = pretrain_cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)
@@ -380,6 +388,9 @@ def main():
         return spawn_ranks(a.gpus)            # before anything touches the GPU: the children are fresh processes
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if os.environ.get('DSRG_BENCH_HANG_DUMP'):          # debugging aid: Python stacks of every rank after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['DSRG_BENCH_HANG_DUMP']), exit=True)
     if world != a.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, world))
     if os.environ.get('DSRG_BENCH_SPAWN_SELFTEST') == '1':

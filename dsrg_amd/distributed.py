@@ -92,8 +92,10 @@ def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_g
     from . import functional as _Fn
     _Fn.MATERIALIZE_UNUSED_GRADS = True        # see functional._PackFn
     ids = [device.index] if (device is not None and device.type == 'cuda') else None
+    bucket_cap_mb = int(os.environ.get('DSRG_DDP_BUCKET_MB', bucket_cap_mb))            # debugging aids
+    as_view = os.environ.get('DSRG_DDP_BUCKET_VIEW', '1') == '1'
     ddp = DDP(model, device_ids=ids, find_unused_parameters=not static_graph, static_graph=static_graph,
-              bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+              bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=as_view)
     if bf16_grads:
         ddp.register_comm_hook(None, bf16_compress_hook)
     return ddp
