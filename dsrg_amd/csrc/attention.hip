@@ -171,13 +171,19 @@ __device__ unsigned long long g_attn_stamps[16384 * 4];
 #ifndef ATTN_MFMA_MIN_WAVES
 #define ATTN_MFMA_MIN_WAVES 3
 #endif
-template <bool DROP>
-__global__ __launch_bounds__(256, DROP ? 2 : ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
+// SPREL: the spatial bias w * d + b of the workgroup's [64 queries x 128 keys] block is staged in LDS with the K / V tiles
+// (coalesced 256-byte row pieces, one affine per element) and read back as one ds_read_b128 per score tile, instead of four
+// scattered global loads per tile and lane (graph_sprels, vilmodel.py:757-759; launches without pair distances use the
+// instantiation without the 33 KiB table).
+constexpr int SPS = 132;      // floats per row of the bias table: rows 4 banks apart, conflict-free b128 reads
+template <bool DROP, bool SPREL>
+__global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
   ATTN_STAMP(0);
   ATTN_PICK_PROBLEM(grp)
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
   __shared__ float mt[KC];
+  __shared__ __attribute__((aligned(16))) float sp[SPREL ? 64 * SPS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(256, DROP ? 2 : ATTN_MFMA_MIN_WAVES) void attention
     qf[1] = *reinterpret_cast<const uint4*>(Qp + (size_t)qrow * a.q_rs + 32 + g * 8);
   }
   const float sw = a.dists ? a.sprel_w[0] : 0.f, sb = a.dists ? a.sprel_b[0] : 0.f;
-  const float* drow = a.dists ? a.dists + ((size_t)b * a.Nq + (qrow < a.Nq ? qrow : 0)) * a.Nk : nullptr;
+  const float* drow = (!SPREL && a.dists) ? a.dists + ((size_t)b * a.Nq + (qrow < a.Nq ? qrow : 0)) * a.Nk : nullptr;
+  const bool use_sp = SPREL && a.dists != nullptr;              // workgroup-uniform (a grouped launch may mix problems)
 
   f32x4 o[4];
 #pragma unroll
@@ -223,11 +230,31 @@ __global__ __launch_bounds__(256, DROP ? 2 : ATTN_MFMA_MIN_WAVES) void attention
         vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + min(key, nk - 1)) * a.v_rs + (dc0 + 2 * p) * 8);
       uint8_t mkb = 1;
       if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + k0 + min(tid & (KC - 1), nk - 1)];
+      float dreg[SPREL ? 32 : 1];
+      if constexpr (SPREL) {
+        if (use_sp) {          // wave w stages rows 16w .. 16w+15 of the block: two 256-byte pieces per row
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float* dr = a.dists + ((size_t)b * a.Nq + min(bx * 64 + wave * 16 + i, a.Nq - 1)) * a.Nk + k0;
+            dreg[2 * i] = dr[min(lane, nk - 1)];
+            dreg[2 * i + 1] = dr[min(lane + 64, nk - 1)];
+          }
+        }
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = r + 32 * p;
         if (row < ntile * 16)
           *reinterpret_cast<uint4*>(Ks + kswz(row, c)) = row < nk ? kreg[p] : make_uint4(0, 0, 0, 0);
+      }
+      if constexpr (SPREL) {
+        if (use_sp) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sp[(wave * 16 + i) * SPS + lane] = dreg[2 * i] * sw + sb;
+            sp[(wave * 16 + i) * SPS + 64 + lane] = dreg[2 * i + 1] * sw + sb;
+          }
+        }
       }
       if (key < ntile * 16) {
 #pragma unroll
@@ -280,7 +307,13 @@ __global__ __launch_bounds__(256, DROP ? 2 : ATTN_MFMA_MIN_WAVES) void attention
     for (int t = 0; t < NTL; ++t) {
       {
         const float4 mk = *reinterpret_cast<const float4*>(&mt[t * 16 + 4 * g]);
-        const float mm[4] = {mk.x, mk.y, mk.z, mk.w};
+        float mm[4] = {mk.x, mk.y, mk.z, mk.w};
+        if constexpr (SPREL) {
+          if (use_sp) {        // padding keys carry -inf in mt: the (finite, clamped) table entry does not matter there
+            const float4 d4 = *reinterpret_cast<const float4*>(&sp[(wave * 16 + c16) * SPS + t * 16 + 4 * g]);
+            mm[0] += d4.x; mm[1] += d4.y; mm[2] += d4.z; mm[3] += d4.w;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = s[t][r] * a.scale + mm[r];
@@ -994,9 +1027,16 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
   dim3 grid(blocks, NH, B), block(256);
   const bool drop = p_drop > 0.f;      // the dropout variants are separate instantiations: the inference kernels carry none of it
   hipStream_t st = (hipStream_t)stream;
+  bool any_dists = false;
+  for (int i = 0; i < grp.n; ++i) any_dists = any_dists || grp.a[i].dists != nullptr;
   if (mfma_ok) {
-    if (drop) hipLaunchKernelGGL((attention_mfma_kernel<true>), grid, block, 0, st, grp);
-    else hipLaunchKernelGGL((attention_mfma_kernel<false>), grid, block, 0, st, grp);
+    if (any_dists) {
+      if (drop) hipLaunchKernelGGL((attention_mfma_kernel<true, true>), grid, block, 0, st, grp);
+      else hipLaunchKernelGGL((attention_mfma_kernel<false, true>), grid, block, 0, st, grp);
+    } else {
+      if (drop) hipLaunchKernelGGL((attention_mfma_kernel<true, false>), grid, block, 0, st, grp);
+      else hipLaunchKernelGGL((attention_mfma_kernel<false, false>), grid, block, 0, st, grp);
+    }
   } else if (dtype == DSRG_F32) {
     if (drop) hipLaunchKernelGGL((attention_kernel<float, true>), grid, block, 0, st, grp);
     else hipLaunchKernelGGL((attention_kernel<float, false>), grid, block, 0, st, grp);

@@ -44,6 +44,35 @@ def test_gemm(K, dtype, M, N, K_, act, res, of32):
     assert err <= tol * max(1.0, scale), (err, tol, scale)
 
 
+TILE_MENU = [(64, 64, 2), (64, 64, 3), (64, 64, 4), (64, 128, 2), (64, 128, 3), (64, 192, 3), (64, 256, 3), (128, 64, 2), (128, 64, 3),
+             (128, 64, 4), (128, 96, 3), (128, 128, 2), (128, 128, 3), (128, 192, 2), (128, 192, 3), (128, 256, 3), (256, 128, 2), (256, 128, 3)]
+
+
+@pytest.mark.parametrize('M,N,K_,act,res,of32', [(513, 330, 896, 1, False, False), (2432, 768, 768, 0, True, True), (300, 1000, 128, 2, True, False),
+                                                  (1, 64, 3072, 0, False, False)])
+def test_gemm_tile_menu(K, M, N, K_, act, res, of32):
+    """every tile / ring depth of the bf16 menu through dsrg_gemm_nt_tiled (the 8-wave 256x128 tile, the two-pass epilogue
+    of its 2-deep form, the odd 96- and 192-column tiles): same result as the plan's tile, which test_gemm checks against
+    torch; partial tiles on every edge."""
+    dtype = torch.bfloat16
+    x, w, b = _r(M, K_, dtype=dtype), _r(N, K_, seed=1, scale=0.05, dtype=dtype), _r(N, seed=2)
+    r = _r(M, N, seed=3, dtype=dtype) if res else None
+    ref = ACTS[act](x.float() @ w.float().T + b) + (r.float() if res else 0)
+    tol = (1e-3 * math.sqrt(K_) / 16 if of32 else 3e-2) * max(1.0, ref.abs().max().item())
+    base = K.gemm([(x, w, b, r)], act, of32)[0]
+    assert (base.float() - ref).abs().max().item() <= tol
+    for t in TILE_MENU:
+        out = K.gemm([(x, w, b, r)], act, of32, tile=t)[0]
+        assert out.dtype == base.dtype
+        # same K order and fp32 accumulation in every tile: equal up to the GELU / rounding of identical sums
+        assert (out.float() - base.float()).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item()) + (0 if of32 else 1e-2 * tol), t
+    # grouped: two problems of different shape in one launch of the 8-wave tile
+    x2, w2 = _r(77, K_, seed=5, dtype=dtype), _r(200, K_, seed=6, scale=0.05, dtype=dtype)
+    o = K.gemm([(x, w, b, r), (x2, w2, None, None)], act, of32, tile=(256, 128, 3))
+    assert (o[0].float() - ref).abs().max().item() <= tol
+    assert (o[1].float() - ACTS[act](x2.float() @ w2.float().T)).abs().max().item() <= tol
+
+
 def _ln_fold(w, b, gamma, beta, dtype):
     """(W * gamma in the storage dtype, c1 = row sums of that, bias + W beta): dsrg_gemm_problem_t, a_stats"""
     wf = (w.float() * gamma[None]).to(dtype)
