@@ -179,6 +179,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self._side_stream, self.overlap_streams, self._fork_depth = None, True, 0
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams (3.6 % faster than grouped launches at R2R shapes; 0 = grouped)
         self.split_when_eager = False          # bench.py sets it to trace the captured schedule's launches eagerly
+        self.split_max_ratio = float(os.environ.get('DSRG_SPLIT_MAX_RATIO', '4.0'))
         # inference: the LayerNorms inside the x-layers are folded into the neighbouring GEMM epilogues (_x_layers_fused)
         self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '1') == '1'
         self._fold = None
@@ -739,12 +740,13 @@ class GlocalTextPathNavCMT(nn.Module):
         v = vj()
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
-        # two streams pay when the branches are of similar size (R2R: 20 vs 38 tokens); with one much longer branch
-        # (REVERIE: 20 vs 58) the grouped launches are faster (measured, bench.py --config c3)
+        # two streams pay at R2R's 20 vs 38 tokens and, with round 2's 64x64x3 GEMM plan, at REVERIE's 20 vs 58 too
+        # (bench.py --config c3: 1.762 ms grouped, 1.649 ms split; round 1's plan had it the other way round); beyond a
+        # 4:1 imbalance the grouped launches are kept
         # (under HIP-graph capture only: launched eagerly from Python the step is host-bound and the 40 % more launches
         # of the split schedule cost 3 %)
         if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
-                and max(G, Vp) <= 2.7 * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
+                and max(G, Vp) <= self.split_max_ratio * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
             lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
             g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
             v = lj()
