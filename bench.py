@@ -289,7 +289,8 @@ def pretrain_main(a, dtype, dev, rank, world):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': 'BASELINE config[3]: R2R pre-training step, forward+backward+clip+AdamW, %s' % a.dtype, 'name': 'c4',
                           'trajectories_per_gpu': PT_B, 'txt_len': PT_L, 'trajectory_steps_total': nsteps, 'dropout': cfg.hidden_dropout_prob,
-                          'parallelism': 'DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if world > 1 else 'single GPU'},
+                          'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else
+                                          'DDP x%d (rehearsal: gloo, gradient buckets staged through host memory)' % world) if world > 1 else 'single GPU'},
                'final_losses': {t: float(v) for t, v in last.items()}}
         if not a.no_roofline:
             # DDP hooks must not fire during the replayed step: run it on the bare module

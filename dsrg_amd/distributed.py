@@ -62,6 +62,8 @@ def broadcast_task_id(task_id, device='cpu'):
     """rank 0 picks the task, everyone follows (pretrain_src/data/loader.py:47-51)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return int(task_id)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([int(task_id)], dtype=torch.int64, device=device)
     dist.broadcast(t, 0)
     return int(t.item())
@@ -83,6 +85,21 @@ def bf16_compress_hook(process_group, bucket):
     return fut.then(decompress)
 
 
+def cpu_staged_allreduce_hook(process_group, bucket):
+    """DDP comm hook for the REHEARSAL backend only (gloo with the model on a GPU, e.g. two ranks sharing the one GPU of a
+    test box): gloo's own path for large CUDA tensors stalls on this pool (a plain 768 MB nn.Sequential under DDP stalls in
+    its first broadcast, tools/dbg/gloo_cuda.py), so the bucket is staged through host memory and reduced there.  Slow and
+    synchronous by design; RCCL runs never take it."""
+    group = process_group if process_group is not None else dist.group.WORLD
+    buf = bucket.buffer()
+    cpu = buf.detach().to('cpu', torch.float32)
+    dist.all_reduce(cpu, group=group)
+    buf.copy_(cpu.div_(dist.get_world_size(group)).to(buf.dtype))
+    fut = torch.futures.Future()
+    fut.set_result(buf)
+    return fut
+
+
 def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_graph=False, force=False):
     """DDP with the reference's semantics.  Larger buckets than torch's 25 MB default: xGMI links are point to point
     (~153 GB/s each), so fewer, larger all-reduces amortise the per-collective latency."""
@@ -92,11 +109,15 @@ def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_g
     from . import functional as _Fn
     _Fn.MATERIALIZE_UNUSED_GRADS = True        # see functional._PackFn
     ids = [device.index] if (device is not None and device.type == 'cuda') else None
-    bucket_cap_mb = int(os.environ.get('DSRG_DDP_BUCKET_MB', bucket_cap_mb))            # debugging aids
-    as_view = os.environ.get('DSRG_DDP_BUCKET_VIEW', '1') == '1'
+    rehearsal = dist.get_backend() == 'gloo' and device is not None and device.type == 'cuda'
+    # rehearsal: no initial broadcast / buffer sync through gloo's CUDA path either (see cpu_staged_allreduce_hook); the
+    # caller loads the same weights on every rank
+    extra = {'init_sync': False, 'broadcast_buffers': False} if rehearsal else {}
     ddp = DDP(model, device_ids=ids, find_unused_parameters=not static_graph, static_graph=static_graph,
-              bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=as_view)
-    if bf16_grads:
+              bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, **extra)
+    if rehearsal:
+        ddp.register_comm_hook(None, cpu_staged_allreduce_hook)
+    elif bf16_grads:
         ddp.register_comm_hook(None, bf16_compress_hook)
     return ddp
 

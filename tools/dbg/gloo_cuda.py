@@ -1,7 +1,7 @@
 import os, sys, time, torch, torch.distributed as dist, torch.multiprocessing as mp
 def run(rank):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', RANK=str(rank), WORLD_SIZE='2')
-    import faulthandler; faulthandler.dump_traceback_later(50, exit=True)
+    import faulthandler; faulthandler.dump_traceback_later(100, exit=True)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo')
     for n in (1 << 10, 1 << 20, 25 << 20):
@@ -9,9 +9,10 @@ def run(rank):
         torch.cuda.synchronize(); t0 = time.time()
         dist.all_reduce(t); torch.cuda.synchronize()
         print(rank, 'allreduce', n * 4 >> 20, 'MiB', '%.3f s' % (time.time() - t0), float(t[0]), flush=True)
-    m = torch.nn.Linear(1024, 1024).cuda()
-    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True, gradient_as_bucket_view=True)
-    ddp(torch.randn(8, 1024, device='cuda')).sum().backward(); torch.cuda.synchronize()
+    m = torch.nn.Sequential(*[torch.nn.Linear(4096, 4096) for _ in range(int(os.environ.get('NL', '1')))]).cuda()
+    print(rank, 'params MB', sum(p.numel() for p in m.parameters()) * 4 >> 20, flush=True)
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True, gradient_as_bucket_view=True, bucket_cap_mb=100)
+    ddp(torch.randn(8, 4096, device='cuda')).sum().backward(); torch.cuda.synchronize()
     print(rank, 'ddp ok', flush=True)
     dist.destroy_process_group()
 if __name__ == '__main__':
