@@ -167,8 +167,12 @@ def _gemm_grads(items):
     trs = K.transpose_pad_grouped(tr) if tr else []
     dxp = [(p[0], trs[p[1]], None, None) for p in dxp]
     dwp = [(trs[p[0]], trs[p[1]], None, None) for p in dwp]
-    dxs = K.gemm(dxp) if dxp else []
-    dws = K.gemm(dwp) if dwp else []
+    if dxp and dwp and len(dxp) + len(dwp) <= _lib.MAX_GROUPS:
+        both = K.gemm(dxp + dwp)            # dgrad and wgrad problems of this backward in ONE grouped launch
+        dxs, dws = both[:len(dxp)], both[len(dxp):]
+    else:
+        dxs = K.gemm(dxp) if dxp else []
+        dws = K.gemm(dwp) if dwp else []
     outx, outw = [], []
     for x, w, dy, ndx, ndw, ndb in items:
         outx.append(dxs.pop(0) if ndx else None)
