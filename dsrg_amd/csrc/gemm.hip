@@ -40,6 +40,10 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Swizzle of a TRANSPOSED operand's stage (rows = contraction index): a 32-lane half of ds_read_b64_tr_b16 takes the same
+// 32-byte column pair of rows r..r+3 and r+8..r+11 (r % 4 == 0); even / odd rows already sit in different halves of the 64
+// banks, so the pair index is XORed with (row bit 1, row bit 3): the 8 rows then cover 8 different 32-byte bank groups.
+__device__ __forceinline__ int swt(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
 
 template <bool SHORT_GELU>
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -56,9 +60,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // WAVES_M x WAVES_N waves (2x2 = 256 threads for every tile but the 256x128 one, which runs 4x2 = 512 threads: two waves
 // per SIMD of 64x64 each, so that a workgroup that owns its CU still has a second wave per SIMD to issue LDS reads and
 // DMAs while the first one's MFMAs run).
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2>
+// TRANS: operand storage of the backward GEMMs (dsrg_gemm_problem_t::trans; bf16, 64x64 tile only).  Bit 0: A is stored
+// [K, M] (contraction-major rows), bit 1: W is stored [K, N].  A transposed operand's stage is 64 contraction rows x 64
+// output columns (again 128-byte rows, the same DMA pieces); its MFMA fragments come out of LDS through the gfx950
+// transposing read ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group, two reads = the 8 k values a lane holds),
+// so dX = dY.W (TRANS 2) and dW = dY^T.X (TRANS 3) need no transposed copy of W, dY or X in HBM.
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const GemmArgs args) {
   GEMM_STAMP(0);
+  constexpr bool TA = (TRANS & 1) != 0, TW = (TRANS & 2) != 0;
+  static_assert(TRANS == 0 || (BM == 64 && BN == 64 && sizeof(T) == 2 && !FUSE), "transposed operands: bf16, 64x64 tile");
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
@@ -187,8 +198,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   for (int i = 0; i < LPS; ++i) {
     const int row = (i * NWAVES + wave) * 8 + (lane >> 3);  // row of the stage
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    if (i < LPA) voff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(P.lda * (int)sizeof(T)) + chunk * 16;
-    else voff[i] = (unsigned)min(n0 + row - BM, N - 1) * (unsigned)(P.ldw * (int)sizeof(T)) + chunk * 16;
+    if (i < LPA) {
+      if constexpr (TA) {     // row = contraction row of the stage; the 16-byte chunk holds 8 output rows (clamped whole: M % 8 == 0)
+        const int col = min(m0 + (((lane & 7) ^ swt(row)) << 3), M - 8);
+        voff[i] = (unsigned)row * (unsigned)(P.lda * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
+      } else voff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(P.lda * (int)sizeof(T)) + chunk * 16;
+    } else {
+      if constexpr (TW) {
+        const int rw = row - BM;
+        const int col = min(n0 + (((lane & 7) ^ swt(rw)) << 3), N - 8);
+        voff[i] = (unsigned)rw * (unsigned)(P.ldw * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
+      } else voff[i] = (unsigned)min(n0 + row - BM, N - 1) * (unsigned)(P.ldw * (int)sizeof(T)) + chunk * 16;
+    }
+  }
+  // TRANS 3 only: K (the rows of both operands) need not be a multiple of 64.  The last, partial K-step fetches rows
+  // >= krem from row 0 of the step instead (valid memory, finite unless the operand itself is not) and the A rows among
+  // them are zeroed in LDS once they have landed (land()): 0 x finite adds nothing.
+  const int krem = TRANS == 3 ? (K & (BK - 1)) : 0;
+  unsigned voff_last[TRANS == 3 ? LPS : 1];
+  if constexpr (TRANS == 3) {
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+      const int row = ((i * NWAVES + wave) * 8 + (lane >> 3)) & (BK - 1);
+      voff_last[i] = (krem && row >= krem) ? voff[i] - (unsigned)row * (unsigned)((i < LPA ? P.lda : P.ldw) * (int)sizeof(T)) : voff[i];
+    }
   }
   // The DMA is issued from inline asm on purpose: hipcc does not count asm memory operations, so it cannot
   // drain the ring with a vmcnt(0) in front of the fragment reads (it does for the builtin form); completion is
@@ -196,10 +229,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
   auto issue1 = [&](int i, int stage, int k0) {
     const unsigned dst = ldsw + stage * TILE_BYTES + i * (NWAVES * 1024);
-    const T* base = (i < LPA ? A : W) + k0;
-    unsigned keep;
+    const T* base = i < LPA ? (TA ? A + (size_t)k0 * P.lda : A + k0) : (TW ? W + (size_t)k0 * P.ldw : W + k0);
+    unsigned keep, vo = voff[i];
+    if constexpr (TRANS == 3) vo = (k0 + BK > K) ? voff_last[i] : vo;       // uniform condition: the partial last K-step
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[i]), "s"(base), "s"(dst) : "memory");
+                 : "=&s"(keep) : "v"(vo), "s"(base), "s"(dst) : "memory");
   };
   auto issue = [&](int stage, int k0) {
 #pragma unroll
@@ -212,14 +246,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
+  const int nk = (K + BK - 1) / BK;          // K % BK != 0 only with TRANS 3 (host-checked)
+  // TRANS bit 0: column sums of the A operand (the bias gradient that goes with dW = dY^T.X), by the waves that own the
+  // tile's rows in the first column of tiles: one more MFMA per A fragment against a fragment of ones.
+  f32x4 accdb[TA ? MT : 1];
+  bool dbw = false;
+  if constexpr (TA) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) accdb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dbw = __builtin_amdgcn_readfirstlane((int)(P.a_colsum != nullptr && tn == 0 && wn == 0)) != 0;
+  }
+  const uint4 ones4 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
   constexpr int D = NST - 1;                 // prefetch distance in K-steps
   // One fragment read (index r < MT+NT: A-fragment r, or W-fragment r-MT) of half K-step `kk` of a stage.
   auto rd1 = [&](uint4 (&fa)[MT], uint4 (&fw)[NT], int r, int stage, int kk) {
     const char* sa = smem + stage * TILE_BYTES;
     const int chunk = q + 4 * kk;
-    if (r < MT) fa[r] = *reinterpret_cast<const uint4*>(sa + swz(wm * WM + r * 16 + r16, chunk));
-    else fw[r - MT] = *reinterpret_cast<const uint4*>(sa + BM * ROWB + swz(wn * WN + (r - MT) * 16 + r16, chunk));
+    // transposed stage: this lane's group (q) takes k rows 32kk+8q .. +7 as two 4-row blocks of the fragment's 16 columns;
+    // the lane supplies the address of block row (r16 >> 2), columns 4 (r16 & 3) .. +3, and receives column r16
+    auto trd = [&](const char* tile, int col16) -> uint4 {
+      typedef short v4s __attribute__((ext_vector_type(4)));
+      const int krow = 32 * kk + 8 * q + (r16 >> 2);
+      const int c = (col16 >> 3) + ((r16 & 3) >> 1);
+      const char* p = tile + krow * ROWB + ((c ^ swt(krow)) << 4) + ((r16 & 1) << 3);     // rows +4: same swizzle, +512 bytes
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * ROWB));
+      const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      return make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    if (r < MT) {
+      if constexpr (TA) fa[r] = trd(sa, wm * WM + r * 16);
+      else fa[r] = *reinterpret_cast<const uint4*>(sa + swz(wm * WM + r * 16 + r16, chunk));
+    } else {
+      if constexpr (TW) fw[r - MT] = trd(sa + BM * ROWB, wn * WN + (r - MT) * 16);
+      else fw[r - MT] = *reinterpret_cast<const uint4*>(sa + BM * ROWB + swz(wn * WN + (r - MT) * 16 + r16, chunk));
+    }
   };
   // The bf16 MFMA is an asm statement with the accumulator tied to an AGPR: (1) the register allocator otherwise
   // shuttles the 128-192 accumulator registers of the 256-row tiles between the two register files once the
@@ -236,6 +297,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[e], pa[e], c, 0, 0, 0);
     }
   };
+  // Column-sum MFMA (ones x A fragment).  The compiler materialises the constant fragment with VALU moves right in front of
+  // the statement and cannot see that an MFMA reads it: the s_nop covers the VALU-write -> MFMA-read distance (measured:
+  // without it the first of two such MFMAs read stale registers).
+  auto mfma_db = [&](const uint4& fa, f32x4& c) {
+    if constexpr (sizeof(T) == 2) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                   : "+a"(c) : "v"(__builtin_bit_cast(u32x4, ones4)), "v"(__builtin_bit_cast(u32x4, fa)));
+    }
+  };
   // Half a K-step: the MT*NT MFMAs on (fa, fw), with the MT+NT fragment reads of the NEXT half step (into na, nw) and
   // the refill DMAs [P0, P1) of a stage spread evenly between them - a workgroup that is alone on its CU (the 256-row
   // tiles) has no other wave to hide LDS latency or DMA issue behind, so the overlap has to be inside the wave.  A DMA
@@ -246,6 +317,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     constexpr int P0 = decltype(p0_tag)::value, P1 = decltype(p1_tag)::value, NP = P1 - P0;
     constexpr int NM = MT * NT, R = MT + NT;
     int r = 0, d = 0;
+    // The column-sum MFMAs go FIRST: the compiler may move accdb between registers at a phase boundary, and it does not
+    // know an asm MFMA is still writing it - the NM MFMAs below are the cover for that.
+    if constexpr (TA) {
+      if (dbw) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mfma_db(fa[i], accdb[i]);
+      }
+    }
 #pragma unroll
     for (int idx = 0; idx < NM; ++idx) {
 #if DSRG_ABLATE != 2
@@ -268,6 +347,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   // finished READING stage st-1 (its fragment loads are waited for first), so that buffer is refilled right away.
   auto land = [&](int st) {
     const int younger = min(D - 1, nk - 1 - st);
+    if constexpr (TRANS == 3) {
+      if (krem && st == nk - 1) {              // this wave's own DMAs are done: zero the A rows past K that it fetched
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* sa = smem + (st % NST) * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < LPA; ++i) {
+          const int row = (i * NWAVES + wave) * 8 + (lane >> 3);
+          if (row >= krem) *reinterpret_cast<uint4*>(sa + row * ROWB + ((lane & 7) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
     if (D >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPS) : "memory");
     else if (D >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -320,6 +410,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     cur = nxt;
   }
   half(fa0, fw0, fa1, fw1, cur, 1, Z{}, Z{}, 0, 0);
+  if constexpr (TA) {
+    if (dbw) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) mfma_db(fa1[i], accdb[i]);
+    }
+  }
 #if DSRG_ABLATE != 2
 #pragma unroll
   for (int idx = 0; idx < MT * NT; ++idx) mfma1(fa1[idx / NT], fw1[idx % NT], acc[idx / NT][idx % NT]);
@@ -328,6 +424,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   // the asm MFMAs are invisible to the compiler's hazard recogniser: cover the XDL-write -> VALU/LDS-read distance
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+  if constexpr (TA) {        // D[i][j] = sum_k ones[i][k] * A[k][j]: every register of a lane is the column sum of its A column r16
+    if (dbw && q == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WM + i * 16 + r16;
+        if (m < M) P.a_colsum[m] = accdb[i][0];
+      }
+    }
+  }
   // ---- epilogue.  A lane holds C[m][n..n+3] for 16 different rows per store, i.e. 32/64-byte row pieces: written
   // straight to HBM that pattern, not the K loop, bounds these mid-size GEMMs.  The raw accumulators therefore go
   // through LDS (fp32 [BM][BN] image over the drained ring, 16-B chunk index XOR (row & 7): conflict-free both ways)
@@ -478,13 +583,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #endif
 }
 
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2>
+template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
   constexpr int smem_main = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
   constexpr int smem = smem_main;
-  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N>), smem);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N>), dim3(total_tiles), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
+  DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), smem);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), dim3(total_tiles), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
   return DSRG_OK;
 }
@@ -566,7 +671,7 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     minK = a.p[i].K < minK ? a.p[i].K : minK;
   }
   bool fuse = false;
-  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
+  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out || a.p[i].trans;   // 64x64-only kernels
   if (!fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) {
     if (bf16) { bm = 256; bn = 128; nst = 3; } else { bm = 128; bn = 128; nst = 2; }
   } else {
@@ -603,6 +708,16 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
   }
   bool fuse = false;
   for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
+  if (a.p[0].trans) {      // backward GEMMs on operands as they lie (no transposed copies); bf16 checked by the entry
+    DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
+    if constexpr (sizeof(T) == 2) {
+      const int tr = a.p[0].trans;
+#define DSRG_TRANS_CASE(TR_, NST_) if (tr == TR_ && nst == NST_) return launch<T, OutT, 64, 64, NST_, false, 2, 2, TR_>(a, tiles, s)
+      DSRG_TRANS_CASE(1, 2); DSRG_TRANS_CASE(1, 3); DSRG_TRANS_CASE(2, 2); DSRG_TRANS_CASE(2, 3); DSRG_TRANS_CASE(3, 2); DSRG_TRANS_CASE(3, 3);
+#undef DSRG_TRANS_CASE
+    }
+    DSRG_CHECK(false, "dsrg_gemm_nt: no kernel for trans=%d", a.p[0].trans);
+  }
   if (fuse) {
     DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: the LayerNorm-fusion epilogue exists for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
     if (nst == 2) return launch<T, OutT, 64, 64, 2, true>(a, tiles, s);
@@ -647,13 +762,21 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
     DSRG_CHECK(p.M >= 0 && p.N >= 0 && p.K > 0, "dsrg_gemm_nt: problem %d has bad dims %dx%dx%d", i, p.M, p.N, p.K);
     if (p.M == 0 || p.N == 0) continue;
     DSRG_CHECK(p.A && p.W && p.C, "dsrg_gemm_nt: problem %d has a null A/W/C", i);
-    DSRG_CHECK(p.K % bk == 0, "dsrg_gemm_nt: problem %d K=%d must be a multiple of %d", i, p.K, bk);
-    DSRG_CHECK(p.lda % al == 0 && p.ldw % al == 0 && p.lda >= p.K && p.ldw >= p.K,
-               "dsrg_gemm_nt: problem %d lda=%d/ldw=%d must be >= K and multiples of %d", i, p.lda, p.ldw, al);
+    DSRG_CHECK(p.K % bk == 0 || p.trans == 3, "dsrg_gemm_nt: problem %d K=%d must be a multiple of %d (any K only with trans = 3)", i, p.K, bk);
+    DSRG_CHECK(!p.a_colsum || (p.trans & 1), "dsrg_gemm_nt: problem %d: a_colsum needs a transposed A (trans bit 0)", i);
+    DSRG_CHECK(p.trans >= 0 && p.trans <= 3 && p.trans == problems[0].trans, "dsrg_gemm_nt: problem %d: trans=%d must be 0..3 and the same for the whole group", i, p.trans);
+    DSRG_CHECK(p.trans == 0 || (dtype == DSRG_BF16 && !p.a_stats && !p.r_stats && !p.stats_out && fbm <= 0),
+               "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion or a pinned tile", i);
+    const bool ta = (p.trans & 1) != 0, tw = (p.trans & 2) != 0;
+    // a transposed operand is [K, M] / [K, N]: whole 16-byte chunks of 8 output rows / columns
+    DSRG_CHECK(p.lda % al == 0 && p.lda >= (ta ? p.M : p.K) && (!ta || (p.M % 8 == 0 && p.M >= 8)),
+               "dsrg_gemm_nt: problem %d lda=%d must be a multiple of %d and >= %s (and M %% 8 == 0 when A is stored transposed)", i, p.lda, al, ta ? "M" : "K");
+    DSRG_CHECK(p.ldw % al == 0 && p.ldw >= (tw ? p.N : p.K) && (!tw || (p.N % 8 == 0 && p.N >= 8)),
+               "dsrg_gemm_nt: problem %d ldw=%d must be a multiple of %d and >= %s (and N %% 8 == 0 when W is stored transposed)", i, p.ldw, al, tw ? "N" : "K");
     DSRG_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "dsrg_gemm_nt: problem %d A/W not 16-byte aligned", i);
-    {   // the kernel addresses A and W rows with 32-bit byte offsets from the operand base
+    {   // the kernel addresses A and W rows with 32-bit byte offsets from the operand base (a transposed operand: from the K-step's base)
       const size_t esz = dtype == DSRG_BF16 ? 2 : 4;
-      DSRG_CHECK((size_t)p.M * p.lda * esz < ((size_t)1 << 32) && (size_t)p.N * p.ldw * esz < ((size_t)1 << 32),
+      DSRG_CHECK((size_t)(ta ? 64 : p.M) * p.lda * esz < ((size_t)1 << 32) && (size_t)(tw ? 64 : p.N) * p.ldw * esz < ((size_t)1 << 32),
                  "dsrg_gemm_nt: problem %d: an operand spans 4 GiB or more (M*lda or N*ldw too large)", i);
     }
     DSRG_CHECK(p.ldc >= p.N && (!p.residual || p.ldr >= p.N), "dsrg_gemm_nt: problem %d ldc/ldr < N", i);

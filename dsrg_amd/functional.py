@@ -142,41 +142,71 @@ def _as2d(t):
     return t.as_strided((M, t.shape[-1]), (ld, 1), t.storage_offset())
 
 
+BWD_AS_LIES = __import__('os').environ.get('DSRG_BWD_AS_LIES', '1') == '1'    # A/B knob: 0 = always transposed copies
+
+
+def _lies_ok(t):
+    """a 2-D bf16 operand the transposed-operand GEMM can take as it lies: unit column stride, 16-byte rows and base"""
+    return t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
 def _gemm_grads(items):
-    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw, need_db) -> (dx list, dw list, db list); every
-    group of dgrad / wgrad GEMMs is ONE grouped launch of the forward NT kernel on transposed operands; the bias
-    gradients (column sums of dy) are taken by the kernel that transposes dy, into one zeroed buffer."""
+    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw, need_db) -> (dx list, dw list, db list).
+    bf16 with friendly shapes (the transformer layers): dX = dY.W and dW = dY^T.X run on dY, W and X AS THEY LIE
+    (dsrg_gemm_problem_t::trans = 2 / 3, ds_read_b64_tr_b16 fragments): one grouped launch for the dgrads, one for the wgrads
+    (any row count: the partial last K-step is zero-filled on chip), no transposed copies; db = column sums of dY out of the
+    wgrad launch (a_colsum).  Anything else (fp32 parity mode, ragged rows such as the masked-token
+    heads) goes through the NT kernel on transposed, zero-padded copies (kernels.transpose_pad_grouped, which also takes the
+    bias gradients)."""
     nb = sum(it[1].shape[0] for it in items if it[5])
     dball = K.zeros_f32((nb,), items[0][2].device) if nb else None
     dxp, dwp, dbs, o = [], [], [], 0
+    fdx, fdw, fdb = [], [], []                 # problems on operands as they lie (fdb: where a wgrad's column sums of dY go)
     tr = []                                    # every transpose of this call: one grouped launch
+    slots = []                                 # per item: where its dx / dw come from
     for x, w, dy, ndx, ndw, ndb in items:
         N, Kd = w.shape
+        M = dy.shape[0]
         db = None
         if ndb:
             db = dball[o:o + N]; o += N
+        lies = BWD_AS_LIES and _lies_ok(dy) and _lies_ok(w) and N % 8 == 0 and Kd % 8 == 0 and M > 0
+        sx = sw = None
         if ndx:
-            Np = (N + 63) // 64 * 64
-            dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
-            dxp.append([dyp, len(tr), None, None]); tr.append((w, None))                  # [M,Np] x [K,Np]^T
+            if lies and N % 64 == 0:
+                sx = ('f', len(fdx)); fdx.append((dy, w, None, None))                    # [M,N] x ([N,K] stored [K',N'])
+            else:
+                Np = (N + 63) // 64 * 64
+                dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
+                sx = ('t', len(dxp)); dxp.append([dyp, len(tr), None, None]); tr.append((w, None))   # [M,Np] x [K,Np]^T
         if ndw:
-            dwp.append([len(tr), len(tr) + 1, None, None]); tr += [(dy, db), (x, None)]   # [N,Mp] x [K,Mp]^T
+            if lies and _lies_ok(x):
+                sw = ('f', len(fdw)); fdw.append((dy, x, None, None)); fdb.append(db)    # dY [M,N] = [K',M'], X [M,K] = [K',N']
+            else:
+                sw = ('t', len(dwp)); dwp.append([len(tr), len(tr) + 1, None, None]); tr += [(dy, db), (x, None)]   # [N,Mp] x [K,Mp]^T
         elif ndb:
-            db.copy_(K.colsum(dy))
+            K.colsum(dy, out=db)
         dbs.append(db)
-    trs = K.transpose_pad_grouped(tr) if tr else []
-    dxp = [(p[0], trs[p[1]], None, None) for p in dxp]
-    dwp = [(trs[p[0]], trs[p[1]], None, None) for p in dwp]
-    if dxp and dwp and len(dxp) + len(dwp) <= _lib.MAX_GROUPS:
-        both = K.gemm(dxp + dwp)            # dgrad and wgrad problems of this backward in ONE grouped launch
-        dxs, dws = both[:len(dxp)], both[len(dxp):]
-    else:
-        dxs = K.gemm(dxp) if dxp else []
-        dws = K.gemm(dwp) if dwp else []
-    outx, outw = [], []
-    for x, w, dy, ndx, ndw, ndb in items:
-        outx.append(dxs.pop(0) if ndx else None)
-        outw.append(dws.pop(0) if ndw else None)
+        slots.append((sx, sw))
+    res = {'f': [None, None], 't': [None, None]}
+    if fdx:
+        res['f'][0] = [K.gemm(fdx[i:i + _lib.MAX_GROUPS], trans=2) for i in range(0, len(fdx), _lib.MAX_GROUPS)]
+        res['f'][0] = [t for g in res['f'][0] for t in g]
+    if fdw:
+        res['f'][1] = [K.gemm(fdw[i:i + _lib.MAX_GROUPS], trans=3, colsums=fdb[i:i + _lib.MAX_GROUPS]) for i in range(0, len(fdw), _lib.MAX_GROUPS)]
+        res['f'][1] = [t for g in res['f'][1] for t in g]
+    if tr:
+        trs = K.transpose_pad_grouped(tr)
+        dxp = [(p[0], trs[p[1]], None, None) for p in dxp]
+        dwp = [(trs[p[0]], trs[p[1]], None, None) for p in dwp]
+        if dxp and dwp and len(dxp) + len(dwp) <= _lib.MAX_GROUPS:
+            both = K.gemm(dxp + dwp)            # dgrad and wgrad problems of this backward in ONE grouped launch
+            res['t'][0], res['t'][1] = both[:len(dxp)], both[len(dxp):]
+        else:
+            res['t'][0] = K.gemm(dxp) if dxp else []
+            res['t'][1] = K.gemm(dwp) if dwp else []
+    outx = [None if sx is None else res[sx[0]][0][sx[1]] for sx, _ in slots]
+    outw = [None if sw is None else res[sw[0]][1][sw[1]] for _, sw in slots]
     return outx, outw, dbs
 
 

@@ -103,14 +103,17 @@ def _rows(t):
     return M, ld
 
 
-def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=None):
+def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=None, trans=0, colsums=None):
     """problems: list of (x [..,K], w [N,K], bias fp32 [N] | None, residual [..,N] | None).
     Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32).  tile=(bm, bn, nst) pins the block tile
     (dsrg_gemm_nt_tiled; tuning only).
     fuse: optional list (one entry per problem, None = plain) of dicts for the LayerNorm-fusion epilogue of
     dsrg_gemm_problem_t: 'a_stats': (partials [M, K/64, 2] fp32, c1 [N] fp32) - x holds an un-normalised row and w / bias
     are the gamma-folded weight and beta-folded bias; 'r_stats': (partials [M, N/64, 2], gamma [N], beta [N]) - the residual
-    is un-normalised; 'stats_out': fp32 [M, N/64, 2] to receive this launch's partials; 'eps'."""
+    is un-normalised; 'stats_out': fp32 [M, N/64, 2] to receive this launch's partials; 'eps'.
+    trans (dsrg_gemm_problem_t::trans, bf16 only): bit 0 - x is stored [K, M]; bit 1 - w is stored [K, N] (2-D tensors, row
+    stride free): the backward GEMMs of a linear layer on dY, W and X as they lie.  colsums (trans bit 0): optional list of
+    fp32 [M] tensors (or None) that receive the column sums of the stored x (= the bias gradient with dW = dY^T.X)."""
     lib = _lib.load()
     n = len(problems)
     arr = (_lib.GemmProblem * n)()
@@ -120,14 +123,23 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
         _dev(x)
         if _dt(x) != dt or w.dtype != x.dtype:
             raise _lib.DsrgHipError('gemm: mixed dtypes in one grouped launch')
-        M, lda = _rows(x)
-        N, K = w.shape
-        if x.shape[-1] != K:
-            raise _lib.DsrgHipError('gemm: x[..,%d] vs w[%d,%d]' % (x.shape[-1], N, K))
+        if trans:
+            if x.dim() != 2 or w.dim() != 2 or x.stride(1) != 1:
+                raise _lib.DsrgHipError('gemm: transposed operands must be 2-D with a contiguous last dim')
+            (K, M), lda = (x.shape, x.stride(0)) if trans & 1 else ((x.shape[1], x.shape[0]), x.stride(0))
+            N, Kw = (w.shape[1], w.shape[0]) if trans & 2 else w.shape
+            oshape = (M, N)
+        else:
+            M, lda = _rows(x)
+            N, Kw = w.shape
+            K = x.shape[-1]
+            oshape = x.shape[:-1] + (N,)
+        if Kw != K:
+            raise _lib.DsrgHipError('gemm: x contracts over %d, w over %d (trans=%d)' % (K, Kw, trans))
         if outs is not None and outs[i] is not None:
             out = outs[i]
         else:
-            out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+            out = torch.empty(oshape, device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
         Mo, ldc = _rows(out)
         ldr = 0
         if r is not None:
@@ -139,6 +151,12 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
         if Mo != M or w.stride(1) != 1:
             raise _lib.DsrgHipError('gemm: bad out rows / weight layout')
         arr[i] = _lib.GemmProblem(_p(x), _p(w), _p(b), _p(r), _p(out), M, N, K, lda, w.stride(0), ldr, ldc)
+        arr[i].trans = trans
+        if colsums is not None and colsums[i] is not None:
+            cs = colsums[i]
+            if not (trans & 1) or cs.dtype != torch.float32 or cs.numel() != M or not cs.is_contiguous():
+                raise _lib.DsrgHipError('gemm: colsums[i] must be contiguous fp32 [M] and needs trans bit 0')
+            arr[i].a_colsum = _p(cs)
         f = fuse[i] if fuse is not None else None
         if f:
             g = arr[i]
@@ -494,12 +512,15 @@ def transpose_pad_grouped(items, pad_to=64):
     return outs
 
 
-def colsum(x):
-    """x [M,N] -> fp32 [N]"""
+def colsum(x, out=None):
+    """x [M,N] -> fp32 [N] (added into `out` when given: a zeroed slice of a gradient buffer)"""
     lib = _lib.load()
     _dev(x)
     M, N = x.shape
-    out = zeros_f32((N,), x.device)
+    if out is None:
+        out = zeros_f32((N,), x.device)
+    elif out.dtype != torch.float32 or out.numel() != N or not out.is_contiguous():
+        raise _lib.DsrgHipError('colsum: out must be contiguous fp32 [N]')
     _lib.check(lib.dsrg_colsum_acc(_p(x), x.stride(0), _p(out), M, N, _dt(x), _stream()), 'dsrg_colsum_acc')
     return out
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 9
+#define DSRG_ABI_VERSION 10
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -62,7 +62,17 @@ typedef struct {
   float* stats_out;
   int32_t a_np, r_np;
   float ln_eps;
-  int32_t reserved_;
+  /* Operand storage for the backward GEMMs of a linear layer (replaces torch.autograd's  dX = dY @ W,  dW = dY.T @ X  for
+   * the nn.Linear calls of FT/vilmodel.py:111-113,195,209; PT/vilmodel.py twins) without transposed copies in HBM.
+   * 0: A [M,K], W [N,K] as above.  Bit 0: A is stored [K, M] (row stride lda >= M); bit 1: W is stored [K, N] (ldw >= N).
+   *   dX[M,K'] = dY[M,N'] . W[N',K']   -> A = dY, W = the weight as it lies ([N',K'] = [K, N] of this GEMM), trans = 2
+   *   dW[N',K'] = dY^T . X             -> A = dY ([M',N'] = [K, M]), W = X ([M',K'] = [K, N]), trans = 3
+   * bf16 only, M (N) % 8 == 0 for a transposed A (W), no LayerNorm fusion; one value per grouped launch.  K % 64 == 0
+   * except with trans = 3 (any K >= 1: the rows past K of the last step are zero-filled on chip).
+   * a_colsum (trans bit 0 only, optional): float [M], receives sum_k A[k, m] - the bias gradient db = column sums of dY
+   * that belongs to dW = dY^T.X - written by plain stores (each m by exactly one workgroup: deterministic). */
+  int32_t trans;
+  float* a_colsum;
 } dsrg_gemm_problem_t;
 int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
                  int act, void* stream);

@@ -73,6 +73,66 @@ def test_gemm_tile_menu(K, M, N, K_, act, res, of32):
     assert (o[1].float() - ACTS[act](x2.float() @ w2.float().T)).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize('M,N,K_', [(2432, 768, 3072), (64, 64, 64), (1288, 3072, 768), (8, 24, 128), (776, 30528, 768), (200, 136, 4096)])
+@pytest.mark.parametrize('of32', [False, True])
+def test_gemm_transposed_operands(K, M, N, K_, of32):
+    """dsrg_gemm_problem_t::trans - the backward GEMMs of a linear layer on operands as they lie: A stored [K, M] and / or W
+    stored [K, N] (strided views included).  Bit-exact against the NT kernel on explicitly transposed copies (same K order,
+    same MFMA), and within bf16 GEMM tolerance of torch."""
+    dtype = torch.bfloat16
+    a = _r(M, K_, dtype=dtype)
+    w = _r(N, K_, seed=1, scale=0.05, dtype=dtype)
+    b = _r(N, seed=2)
+    ref = a.float() @ w.float().T + b
+    base = K.gemm([(a, w, b, None)], 0, of32)[0]
+    tol = (1e-3 * math.sqrt(K_) / 16 if of32 else 3e-2) * max(1.0, ref.abs().max().item())
+    assert (base.float() - ref).abs().max().item() <= tol
+    at_buf = torch.zeros(K_, M + 16, device=a.device, dtype=dtype)       # [K, M] inside a wider buffer: lda > M
+    at_buf[:, :M] = a.T
+    at, wt = at_buf[:, :M], w.T.contiguous()
+    for trans, xa, xw in ((1, at, w), (2, a, wt), (3, at, wt)):
+        out = K.gemm([(xa, xw, b, None)], 0, of32, trans=trans)[0]
+        assert out.shape == base.shape and out.dtype == base.dtype
+        assert torch.equal(out, base), (trans, (out.float() - base.float()).abs().max().item())
+    # grouped: two problems of different shape in one launch
+    a2, w2 = _r(72, K_, seed=5, dtype=dtype), _r(200, K_, seed=6, scale=0.05, dtype=dtype)
+    o = K.gemm([(at, wt, b, None), (a2.T.contiguous(), w2.T.contiguous(), None, None)], 0, of32, trans=3)
+    assert torch.equal(o[0], base)
+    assert torch.equal(o[1], K.gemm([(a2, w2, None, None)], 0, of32)[0])
+
+
+@pytest.mark.parametrize('M,N,K_', [(768, 768, 888), (3072, 768, 4932), (128, 384, 14796), (1000, 768, 1), (768, 1536, 24), (8, 8, 63), (200, 72, 130)])
+def test_gemm_wgrad_any_rows_and_column_sums(K, M, N, K_):
+    """trans = 3 (dW = dY^T.X) with a row count that is no multiple of 64 (the partial last K-step is zero-filled on chip)
+    and the column sums of dY (the bias gradient) from the same launch; bit-exact against the NT kernel on zero-padded
+    transposed copies, column sums against torch in fp32."""
+    dtype = torch.bfloat16
+    dy, x = _r(K_, M, dtype=dtype), _r(K_, N, seed=1, dtype=dtype)
+    Kp = (K_ + 63) // 64 * 64
+    dyt = torch.zeros(M, Kp, device=dy.device, dtype=dtype); dyt[:, :K_] = dy.T
+    xt = torch.zeros(N, Kp, device=dy.device, dtype=dtype); xt[:, :K_] = x.T
+    base = K.gemm([(dyt, xt, None, None)])[0]
+    db = torch.full((M,), 7.0, device=dy.device)          # plain stores: whatever was there is overwritten
+    out = K.gemm([(dy, x, None, None)], trans=3, colsums=[db])[0]
+    assert torch.equal(out, base), (out.float() - base.float()).abs().max().item()
+    ref = dy.float().sum(0)
+    assert (db - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) * math.sqrt(K_)
+    # poisoned memory behind the operands must not leak in: the rows past K_ are never used
+    big = torch.full((K_ + 64, M), float('nan'), device=dy.device, dtype=dtype); big[:K_] = dy
+    bigx = torch.full((K_ + 64, N), float('nan'), device=dy.device, dtype=dtype); bigx[:K_] = x
+    out2 = K.gemm([(big[:K_], bigx[:K_], None, None)], trans=3)[0]
+    assert torch.equal(out2, base)
+
+
+def test_gemm_transposed_operands_rejects_bad_shapes(K):
+    from dsrg_amd import _lib
+    a, w = _r(64, 20, dtype=torch.bfloat16), _r(64, 64, seed=1, dtype=torch.bfloat16)       # M = 20 is not a multiple of 8
+    with pytest.raises(_lib.DsrgHipError):
+        K.gemm([(a, w, None, None)], trans=1)
+    with pytest.raises(_lib.DsrgHipError):
+        K.gemm([(_r(64, 64), _r(64, 64, seed=1), None, None)], trans=3)                       # fp32: no transposed kernels
+
+
 def _ln_fold(w, b, gamma, beta, dtype):
     """(W * gamma in the storage dtype, c1 = row sums of that, bias + W beta): dsrg_gemm_problem_t, a_stats"""
     wf = (w.float() * gamma[None]).to(dtype)
