@@ -83,6 +83,8 @@ SIGNATURES = {
     'dsrg_attention_fwd_grouped': (C.c_int, [C.POINTER(AttnProblem), _I, _I, _P, _P, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_attention_bwd': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
+    'dsrg_attention_bwd_strided': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
+                                             _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_attention_bwd_noalloc': (C.c_int, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _P, _I, _P, _P, _P,
                                              _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),

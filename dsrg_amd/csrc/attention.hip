@@ -414,7 +414,9 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
 struct AttnBwdArgs {
   AttnArgs f;                 // forward operands (O = forward output)
   const void* dO; int64_t do_bs; int do_rs;
-  void *dQ, *dK, *dV;         // contiguous [B,N,NH*64]
+  void *dQ, *dK, *dV;         // [B,N,NH*64] with the batch / row strides below (elements)
+  int64_t dq_bs, dk_bs, dv_bs;
+  int dq_rs, dk_rs, dv_rs;
   float* delta;               // [B,NH,Nq] workspace
   float* dsprel;              // [2] (w, b) accumulated with atomics, or NULL
 };
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs
   const T* Vp = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * DH;
   const T* Op = reinterpret_cast<const T*>(a.O) + b * a.o_bs + h * DH;
   const T* Gp = reinterpret_cast<const T*>(ba.dO) + b * ba.do_bs + h * DH;
-  T* dQp = reinterpret_cast<T*>(ba.dQ) + ((size_t)b * a.Nq) * (a.NH * DH) + h * DH;
+  T* dQp = reinterpret_cast<T*>(ba.dQ) + (size_t)b * ba.dq_bs + h * DH;
   // Global loads are issued unconditionally with clamped row indices and masked afterwards: behind `if (row < N)` the
   // compiler waits for each load before issuing the next, one exposed memory latency per row group.
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs
 #pragma unroll
   for (int i = 0; i < QW; ++i) {
     const int qg = q0 + wave * QW + i;
-    if (qg < a.Nq) Elem<T>::st(dQp + (size_t)qg * (a.NH * DH) + lane, dq[i] * a.scale);
+    if (qg < a.Nq) Elem<T>::st(dQp + (size_t)qg * ba.dq_rs + lane, dq[i] * a.scale);
   }
   if (ba.dsprel && a.dists) {
     gsw = wave_sum(gsw); gsb = wave_sum(gsb);
@@ -644,14 +646,14 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
     }
     __syncthreads();
   }
-  T* dKp = reinterpret_cast<T*>(ba.dK) + ((size_t)b * a.Nk) * (a.NH * DH) + h * DH;
-  T* dVp = reinterpret_cast<T*>(ba.dV) + ((size_t)b * a.Nk) * (a.NH * DH) + h * DH;
+  T* dKp = reinterpret_cast<T*>(ba.dK) + (size_t)b * ba.dk_bs + h * DH;
+  T* dVp = reinterpret_cast<T*>(ba.dV) + (size_t)b * ba.dv_bs + h * DH;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int r = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
     if (k0 + r < a.Nk) {
-      st4(dKp + (size_t)(k0 + r) * (a.NH * DH) + c, *reinterpret_cast<const float4*>(&Ks[r * KPAD + c]));
-      st4(dVp + (size_t)(k0 + r) * (a.NH * DH) + c, *reinterpret_cast<const float4*>(&Vs[r * KPAD + c]));
+      st4(dKp + (size_t)(k0 + r) * ba.dk_rs + c, *reinterpret_cast<const float4*>(&Ks[r * KPAD + c]));
+      st4(dVp + (size_t)(k0 + r) * ba.dv_rs + c, *reinterpret_cast<const float4*>(&Vs[r * KPAD + c]));
     }
   }
 }
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
     }
   }
   if (qok) {
-    bf16_t* dQp = reinterpret_cast<bf16_t*>(ba.dQ) + ((size_t)b * a.Nq + qrow) * (a.NH * DH) + h * DH;
+    bf16_t* dQp = reinterpret_cast<bf16_t*>(ba.dQ) + (size_t)b * ba.dq_bs + (size_t)qrow * ba.dq_rs + h * DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       st4(dQp + dt * 16 + 4 * g, make_float4(dq[dt][0] * a.scale, dq[dt][1] * a.scale, dq[dt][2] * a.scale, dq[dt][3] * a.scale));
@@ -970,8 +972,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
     }
   }
   if (active && key < a.Nk) {
-    bf16_t* dKp = reinterpret_cast<bf16_t*>(ba.dK) + ((size_t)b * a.Nk + key) * (a.NH * DH) + h * DH;
-    bf16_t* dVp = reinterpret_cast<bf16_t*>(ba.dV) + ((size_t)b * a.Nk + key) * (a.NH * DH) + h * DH;
+    bf16_t* dKp = reinterpret_cast<bf16_t*>(ba.dK) + (size_t)b * ba.dk_bs + (size_t)key * ba.dk_rs + h * DH;
+    bf16_t* dVp = reinterpret_cast<bf16_t*>(ba.dV) + (size_t)b * ba.dv_bs + (size_t)key * ba.dv_rs + h * DH;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       st4(dKp + dt * 16 + 4 * g, make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]));
@@ -1064,7 +1066,15 @@ static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void*
                               const uint8_t* kmask, int mask_mode, const float* pair_dists,
                               const float* sprel_w, const float* sprel_b,
                               void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
-                              int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+                              int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream,
+                              const int64_t* gst = nullptr /* dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs or contiguous */) {
+  const int64_t hh = (int64_t)NH * DH;
+  const int64_t dq_bs = gst ? gst[0] : Nq * hh, dq_rs = gst ? gst[1] : hh, dk_bs = gst ? gst[2] : Nk * hh, dk_rs = gst ? gst[3] : hh,
+                dv_bs = gst ? gst[4] : Nk * hh, dv_rs = gst ? gst[5] : hh;
+  DSRG_CHECK(dq_rs >= hh && dk_rs >= hh && dv_rs >= hh && dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0 && dq_bs % 4 == 0 && dk_bs % 4 == 0 &&
+                 dv_bs % 4 == 0 && dq_rs < (1 << 30) && dk_rs < (1 << 30) && dv_rs < (1 << 30) &&
+                 (B <= 1 || (dq_bs >= (int64_t)Nq * hh && dk_bs >= (int64_t)Nk * hh && dv_bs >= (int64_t)Nk * hh)),
+             "dsrg_attention_bwd: gradient strides must be multiples of 4 elements, rows >= NH*64 and batches >= N*NH*64");
   DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_attention_bwd: p_drop=%g out of [0,1)", (double)p_drop);
   DSRG_CHECK(dtype == DSRG_F32 || dtype == DSRG_BF16, "dsrg_attention_bwd: bad dtype %d", dtype);
   DSRG_CHECK(Q && K && V && O && dO && lse && dQ && dK && dV && delta_ws, "dsrg_attention_bwd: null pointer");
@@ -1079,7 +1089,7 @@ static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void*
   if (B == 0 || Nq == 0) return DSRG_OK;
   AttnBwdArgs ba{{Q, K, V, const_cast<void*>(O), q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask,
                   mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH, p_drop, seed},
-                 dO, do_bs, do_rs, dQ, dK, dV, delta_ws, dsprel};
+                 dO, do_bs, do_rs, dQ, dK, dV, dq_bs, dk_bs, dv_bs, (int)dq_rs, (int)dk_rs, (int)dv_rs, delta_ws, dsprel};
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((Nq + QPB - 1) / QPB, NH, B), gk((Nk + KT - 1) / KT, NH, B), block(256);
   // bf16 with 16-byte addressable rows: the matrix-core kernels (64 queries / 64 keys per workgroup)
@@ -1118,6 +1128,19 @@ extern "C" int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const v
                                   int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
   return attention_bwd_impl(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, dO, do_bs, do_rs, lse, kmask, mask_mode, pair_dists,
                             sprel_w, sprel_b, dQ, dK, dV, delta_ws, dsprel, B, NH, Nq, Nk, scale, p_drop, seed, dtype, stream);
+}
+
+extern "C" int dsrg_attention_bwd_strided(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                                          const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                                          const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                                          const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                                          const float* sprel_w, const float* sprel_b,
+                                          void* dQ, int64_t dq_bs, int dq_rs, void* dK, int64_t dk_bs, int dk_rs, void* dV, int64_t dv_bs, int dv_rs,
+                                          float* delta_ws, float* dsprel,
+                                          int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+  const int64_t gst[6] = {dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs};
+  return attention_bwd_impl(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, dO, do_bs, do_rs, lse, kmask, mask_mode, pair_dists,
+                            sprel_w, sprel_b, dQ, dK, dV, delta_ws, dsprel, B, NH, Nq, Nk, scale, p_drop, seed, dtype, stream, gst);
 }
 
 // ---- the allocation-free variant (include/dsrg_hip.h: dsrg_attention_bwd_noalloc).  The delta workspace

@@ -414,6 +414,106 @@ def attention(q, k, v, nh, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=
                        p_drop=p_drop, seed=seed or 0)
 
 
+class _AttentionPackedFn(torch.autograd.Function):
+    """Attention on a packed projection: `packed` is [B,N,3H] = q|k|v (self attention, q is None) or [B,Nk,2H] = k|v (cross
+    attention, separate q).  The backward kernels write dq / dk / dv straight into the column blocks of ONE packed gradient
+    (dsrg_attention_bwd_strided): with plain slices torch.autograd builds that gradient from a zero-fill, a copy and an add
+    per slice - ~250 of the ~1130 launches of a pre-training step."""
+
+    @staticmethod
+    def forward(ctx, packed, q, kmask, dists, sw, sb, nh, mask_mode, scale, p_drop, seed):
+        H = nh * 64
+        if q is None:
+            qq, k, v = packed[..., :H], packed[..., H:2 * H], packed[..., 2 * H:]
+        else:
+            qq, k, v = q, packed[..., :H], packed[..., H:]
+        out, lse = K.attention(qq, k, v, nh, kmask, mask_mode if kmask is not None else MASK_NONE, dists, sw, sb, scale, want_lse=True,
+                               p_drop=p_drop, seed=seed)
+        ctx.cfg = (nh, mask_mode, scale, p_drop, seed)
+        ctx.save_for_backward(packed, q, out, lse, kmask, dists, sw, sb)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        packed, q, out, lse, kmask, dists, sw, sb = ctx.saved_tensors
+        nh, mask_mode, scale, p_drop, seed = ctx.cfg
+        H = nh * 64
+        dp = torch.empty(packed.shape, device=packed.device, dtype=packed.dtype)
+        if q is None:
+            qq, k, v = packed[..., :H], packed[..., H:2 * H], packed[..., 2 * H:]
+            grads = (dp[..., :H], dp[..., H:2 * H], dp[..., 2 * H:])
+        else:
+            qq, k, v = q, packed[..., :H], packed[..., H:]
+            grads = (torch.empty(q.shape, device=q.device, dtype=q.dtype), dp[..., :H], dp[..., H:])
+        _, _, _, dsp = K.attention_bwd(qq, k, v, out, do.to(qq.dtype), lse, nh, kmask, mask_mode, dists, sw, sb, scale, p_drop, seed, grads=grads)
+        dsw = dsb = None
+        if dsp is not None:
+            dsw, dsb = dsp[0:1].reshape(sw.shape).to(sw.dtype), dsp[1:2].reshape(sb.shape).to(sb.dtype)
+        return dp, (grads[0] if q is not None else None), None, None, dsw, dsb, None, None, None, None, None
+
+
+def attention_packed(packed, nh, q=None, kmask=None, mask_mode=MASK_NONE, dists=None, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0,
+                     seed=None):
+    """attention(q, k, v) with q|k|v (q is None) or k|v the column blocks of `packed` (see _AttentionPackedFn)."""
+    H = nh * 64
+    if packed.shape[-1] != (3 if q is None else 2) * H:
+        raise _lib.DsrgHipError('attention_packed: packed last dim %d is not %d x nh*64' % (packed.shape[-1], 3 if q is None else 2))
+    if p_drop > 0.0 and seed is None:
+        seed = dropout_seed()
+    if _needs_grad((packed, q, sprel_w, sprel_b)) and packed.stride(-1) == 1:
+        return _AttentionPackedFn.apply(packed, q, kmask, dists, sprel_w, sprel_b, nh, mask_mode, scale, float(p_drop), seed or 0)
+    if q is None:
+        return attention(packed[..., :H], packed[..., H:2 * H], packed[..., 2 * H:], nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale, p_drop, seed)
+    return attention(q, packed[..., :H], packed[..., H:], nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale, p_drop, seed)
+
+
+def attention_grouped_packed(problems, nh, mask_mode=MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0):
+    """problems: list of (q | None, packed, kmask, dists | None) - attention_grouped for packed projections: one launch when no
+    gradient is needed, one attention_packed call per problem otherwise."""
+    H = nh * 64
+    flat = [t for p in problems for t in p[:2]] + [sprel_w, sprel_b]
+    if _needs_grad(flat) or len(problems) > _lib.ATTN_MAX_GROUPS:
+        return [attention_packed(pk, nh, q, km, mask_mode, d, sprel_w if d is not None else None, sprel_b if d is not None else None, scale,
+                                 p_drop) for q, pk, km, d in problems]
+    sl = [((pk[..., :H], pk[..., H:2 * H], pk[..., 2 * H:]) if q is None else (q, pk[..., :H], pk[..., H:])) + (km, d) for q, pk, km, d in problems]
+    return K.attention_grouped(sl, nh, mask_mode, sprel_w, sprel_b, scale, p_drop, dropout_seed() if p_drop > 0.0 else 0)
+
+
+class _SplitColsFn(torch.autograd.Function):
+    """x [.., sum(widths)] -> column blocks (views); backward = ONE concatenation of the blocks' gradients (plain slices
+    cost a zero-fill + copy per slice and an add per pair in backward)."""
+
+    @staticmethod
+    def forward(ctx, x, widths):
+        ctx.widths, ctx.meta = widths, (x.shape, x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        outs, o = [], 0
+        for w in widths:
+            outs.append(x[..., o:o + w]); o += w
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, dtype, device = ctx.meta
+        if all(g is None for g in gs):
+            return None, None
+        gs = [g.to(dtype) if g is not None else torch.zeros(shape[:-1] + (w,), dtype=dtype, device=device) for g, w in zip(gs, ctx.widths)]
+        return torch.cat(gs, -1), None
+
+
+def split_cols(x, widths):
+    """column blocks of x (views), with a one-kernel backward under autograd"""
+    widths = tuple(int(w) for w in widths)
+    if sum(widths) != x.shape[-1]:
+        raise _lib.DsrgHipError('split_cols: widths %s do not add up to %d' % (widths, x.shape[-1]))
+    if _needs_grad((x,)):
+        return list(_SplitColsFn.apply(x, widths))
+    outs, o = [], 0
+    for w in widths:
+        outs.append(x[..., o:o + w]); o += w
+    return outs
+
+
 def attention_grouped(problems, nh, mask_mode=MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0):
     """problems: list of (q, k, v, kmask, dists|None): one launch when no gradient is needed (the two branches of an
     x-layer), one differentiable call per problem otherwise."""

@@ -271,24 +271,39 @@ def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, spre
     return outs
 
 
-def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125, p_drop=0.0, seed=0):
-    """-> dq, dk, dv (contiguous), dsprel fp32 [2] (or None)"""
+def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, scale=0.125, p_drop=0.0, seed=0, grads=None):
+    """-> dq, dk, dv, dsprel fp32 [2] (or None).  grads: optional (dq, dk, dv) to write into - [B,N,nh*64] views with unit
+    column stride, e.g. the column blocks of one packed d(qkv) buffer (dsrg_attention_bwd_strided); else fresh contiguous."""
     lib = _lib.load()
     B, Nq, _ = q.shape
     Nk = k.shape[1]
     _check_heads(nh, q, k, v, o, do)
     do = do if do.stride(2) == 1 else do.contiguous()
-    dq = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
-    dk = torch.empty(B, Nk, nh * 64, device=q.device, dtype=q.dtype)
-    dv = torch.empty_like(dk)
+    if grads is None:
+        dq = torch.empty(B, Nq, nh * 64, device=q.device, dtype=q.dtype)
+        dk = torch.empty(B, Nk, nh * 64, device=q.device, dtype=q.dtype)
+        dv = torch.empty_like(dk)
+    else:
+        dq, dk, dv = grads
+        _check_heads(nh, dq, dk, dv)
+        if dq.shape[:2] != (B, Nq) or dk.shape[:2] != (B, Nk) or dv.shape[:2] != (B, Nk) or any(t.stride(2) != 1 or t.dtype != q.dtype for t in grads):
+            raise _lib.DsrgHipError('attention_bwd: grads must be [B,Nq|Nk,nh*64] views of the input dtype with unit column stride')
     delta = torch.empty(B, nh, Nq, device=q.device, dtype=torch.float32)
     dsp = zeros_f32((2,), q.device) if dists is not None else None
     bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * t.stride(1)
-    _lib.check(lib.dsrg_attention_bwd(
+    if grads is None:
+        _lib.check(lib.dsrg_attention_bwd(
+            _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
+            _p(do), bs(do), do.stride(1), _p(lse), _p(kmask), mask_mode if kmask is not None else _lib.MASK_NONE, _p(dists),
+            _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), float(p_drop), int(seed),
+            _dt(q), _stream()), 'dsrg_attention_bwd')
+        return dq, dk, dv, dsp
+    _lib.check(lib.dsrg_attention_bwd_strided(
         _p(q), bs(q), q.stride(1), _p(k), bs(k), k.stride(1), _p(v), bs(v), v.stride(1), _p(o), bs(o), o.stride(1),
         _p(do), bs(do), do.stride(1), _p(lse), _p(kmask), mask_mode if kmask is not None else _lib.MASK_NONE, _p(dists),
-        _p(sprel_w), _p(sprel_b), _p(dq), _p(dk), _p(dv), _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), float(p_drop), int(seed),
-        _dt(q), _stream()), 'dsrg_attention_bwd')
+        _p(sprel_w), _p(sprel_b), _p(dq), bs(dq), dq.stride(1), _p(dk), bs(dk), dk.stride(1), _p(dv), bs(dv), dv.stride(1),
+        _p(delta), _p(dsp), B, nh, Nq, Nk, float(scale), float(p_drop), int(seed),
+        _dt(q), _stream()), 'dsrg_attention_bwd_strided')
     return dq, dk, dv, dsp
 
 

@@ -130,11 +130,10 @@ class GlocalTextPathCMT(_Backbone):
             ks = ['x.%s.%d' % (br, i) for br in brs]
             q = Fn.linear_grouped([(t[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(2)])
             kv = Fn.linear_grouped([(ctx[j], W[ks[j] + '.ckv.w'], W[ks[j] + '.ckv.b'], None) for j in range(2)])
-            a = [Fn.attention(q[j], kv[j][..., :H], kv[j][..., H:], nh, cmask[j], MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
+            a = [Fn.attention_packed(kv[j], nh, q[j], cmask[j], MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
             t = self._grouped_res_ln(W, ks, '.co', '.cln', a, t, eps)
             qkv = Fn.linear_grouped([(t[j], W[ks[j] + '.lqkv.w'], W[ks[j] + '.lqkv.b'], None) for j in range(2)])
-            a = [Fn.attention(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], nh, tm, MASK_NEG10000, p_drop=self._attn_p())
-                 for j in range(2)]
+            a = [Fn.attention_packed(qkv[j], nh, None, tm, MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
             t = self._grouped_res_ln(W, ks, '.lso', '.lsln', a, t, eps)
             inter = Fn.linear_grouped([(t[j], W[ks[j] + '.lff1.w'], W[ks[j] + '.lff1.b'], None) for j in range(2)], act=ACT_GELU)
             t = self._grouped_res_ln(W, ks, '.lff2', '.lfln', inter, t, eps)

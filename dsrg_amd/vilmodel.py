@@ -402,7 +402,7 @@ class GlocalTextPathNavCMT(nn.Module):
     def _bert_layer(self, W, key, x, nh, kmask, mode):  # vilmodel.py:226-232
         H, eps = x.shape[-1], self.config.layer_norm_eps
         qkv = Fn.linear(x, W[key + '.qkv.w'], W[key + '.qkv.b'])
-        a = Fn.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], nh, kmask, mode, p_drop=self._attn_p())
+        a = Fn.attention_packed(qkv, nh, None, kmask, mode, p_drop=self._attn_p())
         a = self._dense_res_ln(W, key + '.ao', key + '.aln', a, x, eps)
         i = Fn.linear(a, W[key + '.ff1.w'], W[key + '.ff1.b'], act=ACT_GELU)
         return self._dense_res_ln(W, key + '.ff2', key + '.fln', i, a, eps)
@@ -434,7 +434,7 @@ class GlocalTextPathNavCMT(nn.Module):
         ctx = ctx.to(cd).contiguous()
         q = Fn.linear(x, W['igl.q.w'], W['igl.q.b'])
         kv = Fn.linear(ctx, W['igl.kv.w'], W['igl.kv.b'])
-        aug = Fn.attention(q, kv[..., :H], kv[..., H:], nh, cm.contiguous(), MASK_NEG10000, p_drop=self._attn_p())
+        aug = Fn.attention_packed(kv, nh, q, cm.contiguous(), MASK_NEG10000, p_drop=self._attn_p())
         return Fn.igl_blend(aug, x.contiguous(), W['igl.aug.w'], W['igl.aug.b'], W['igl.ori.w'], W['igl.ori.b'])
 
     # ---------------------------------------------------------------- panorama
@@ -461,8 +461,7 @@ class GlocalTextPathNavCMT(nn.Module):
             k = 'pano.%d' % i
             y = Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5)
             qkv = Fn.linear(y, W[k + '.qkv.w'], W[k + '.qkv.b'])
-            a = Fn.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], nh, masks, MASK_NEGINF,
-                             p_drop=p if self.training else 0.0)       # nn.MultiheadAttention(dropout=hidden_dropout_prob), ops.py:14
+            a = Fn.attention_packed(qkv, nh, None, masks, MASK_NEGINF, p_drop=p if self.training else 0.0)       # nn.MultiheadAttention(dropout=hidden_dropout_prob), ops.py:14
             if self.training and p > 0:
                 x = x + self._drop(Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b']), p)
             else:
@@ -675,17 +674,16 @@ class GlocalTextPathNavCMT(nn.Module):
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
+        kvs = Fn.split_cols(kv, [2 * H] * (kv.shape[-1] // (2 * H)))      # the text K|V panel of every (branch, layer)
         for i in range(nl):
             ks = ['x.%s.%d' % (b, i) for b in brs]
             q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(n)])
-            offs = [((('g', 'l').index(brs[j]) * nl + i) * 2) * H for j in range(n)]
-            a = Fn.attention_grouped([(q[j], kv[..., o:o + H], kv[..., o + H:o + 2 * H], txt_masks, None) for j, o in enumerate(offs)],
-                                     nh, MASK_NEG10000, p_drop=self._attn_p())
+            a = Fn.attention_grouped_packed([(q[j], kvs[('g', 'l').index(brs[j]) * nl + i], txt_masks, None) for j in range(n)],
+                                            nh, MASK_NEG10000, p_drop=self._attn_p())
             feats = self._grouped_res_ln(W, ks, '.co', '.cln', a, feats, eps)
             qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(n)])
-            a = Fn.attention_grouped([(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], masks[j],
-                                       dists if brs[j] == 'g' else None) for j in range(n)], nh, MASK_NEG10000, sw, sb,
-                                     p_drop=self._attn_p())
+            a = Fn.attention_grouped_packed([(None, qkv[j], masks[j], dists if brs[j] == 'g' else None) for j in range(n)],
+                                            nh, MASK_NEG10000, sw, sb, p_drop=self._attn_p())
             feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
             inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(n)], act=ACT_GELU)
             feats = self._grouped_res_ln(W, ks, '.ff2', '.fln', inter, feats, eps)

@@ -317,6 +317,18 @@ int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int
                        const float* sprel_w, const float* sprel_b,
                        void* dQ, void* dK, void* dV, float* delta_ws, float* dsprel,
                        int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+/* The same with batch / row strides (elements) on the three gradients, so that they can be column blocks of ONE packed
+ * buffer - d(qkv) [B,N,3*NH*64] of a BertSelfAttention whose query / key / value projections are one GEMM
+ * (FT/vilmodel.py:111-113), d(kv) [B,Nk,2*NH*64] of a cross attention - and torch.autograd needs no zero-fill, copy and
+ * add per slice to put them together.  Rows >= NH*64 elements, strides multiples of 4 elements. */
+int dsrg_attention_bwd_strided(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
+                               const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
+                               const void* dO, int64_t do_bs, int do_rs, const float* lse,
+                               const uint8_t* kmask, int mask_mode, const float* pair_dists,
+                               const float* sprel_w, const float* sprel_b,
+                               void* dQ, int64_t dq_bs, int dq_rs, void* dK, int64_t dk_bs, int dk_rs, void* dV, int64_t dv_bs, int dv_rs,
+                               float* delta_ws, float* dsprel,
+                               int B, int NH, int Nq, int Nk, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* dsrg_attention_bwd without the workspace argument, for callers that cannot allocate: code under HIP-graph capture,
  * tight serving / fine-tuning loops, harnesses that forbid hipMalloc.  NO counterpart in the reference (its autograd

@@ -768,3 +768,48 @@ def test_attention_dropout(K, dtype, B, nh, Nq, Nk, mode, sprel):
     # a different seed gives a different mask; p = 0 is exactly the plain kernel
     assert not torch.equal(out, K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, p_drop=p, seed=seed + 1))
     assert torch.equal(K.attention(q, k, v, nh, kmask, mode, dists, sw, sb), K.attention(q, k, v, nh, kmask, mode, dists, sw, sb, p_drop=0.0, seed=99))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cross', [False, True])
+def test_attention_packed_backward_matches_sliced(K, dtype, cross):
+    """functional.attention_packed (gradients written straight into the packed d(qkv) / d(kv): dsrg_attention_bwd_strided)
+    against functional.attention on slices of the same packed tensor (torch.autograd assembling the gradient), and
+    functional.split_cols against plain slicing."""
+    from dsrg_amd import functional as Fn
+    B, Nq, Nk, nh = 5, 38, 80 if cross else 38, 12
+    H = nh * 64
+    torch.manual_seed(3)
+    pk0 = (torch.randn(B, Nk, (2 if cross else 3) * H, device='cuda') * 0.5).to(dtype)
+    q0 = (torch.randn(B, Nq, H, device='cuda') * 0.5).to(dtype) if cross else None
+    kmask = torch.arange(Nk, device='cuda')[None] < torch.tensor([Nk, 7, 20, Nk - 1, 33], device='cuda')[:, None]
+    dists = torch.rand(B, Nq, Nk, device='cuda') if not cross else None
+    sw = torch.tensor([[0.3]], device='cuda', requires_grad=True) if not cross else None
+    sb = torch.tensor([0.1], device='cuda', requires_grad=True) if not cross else None
+    go = torch.randn(B, Nq, H, device='cuda').to(dtype)
+    res = []
+    for packed_api in (False, True):
+        pk = pk0.clone().requires_grad_(True)
+        q = q0.clone().requires_grad_(True) if cross else None
+        if sw is not None:
+            sw.grad = sb.grad = None
+        if packed_api:
+            o = Fn.attention_packed(pk, nh, q, kmask, 1, dists, sw, sb)
+        elif cross:
+            o = Fn.attention(q, pk[..., :H], pk[..., H:], nh, kmask, 1, dists, sw, sb)
+        else:
+            o = Fn.attention(pk[..., :H], pk[..., H:2 * H], pk[..., 2 * H:], nh, kmask, 1, dists, sw, sb)
+        o.backward(go)
+        res.append((o.detach(), pk.grad, q.grad if cross else None, sw.grad.clone() if sw is not None else None))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])           # same kernels, same values: only where they are written differs
+    if cross:
+        assert torch.equal(res[0][2], res[1][2])
+    else:
+        assert torch.allclose(res[0][3], res[1][3], rtol=1e-3, atol=1e-4)      # float atomics: order may differ
+    # split_cols: gradient of the blocks = concatenation, missing blocks = zeros
+    x = pk0.clone().requires_grad_(True)
+    widths = [H, pk0.shape[-1] - H]
+    a, b = Fn.split_cols(x, widths)
+    (a.float() * 2).sum().backward()
+    assert torch.equal(x.grad[..., :H], torch.full_like(x.grad[..., :H], 2.0)) and x.grad[..., H:].abs().max().item() == 0.0
