@@ -165,7 +165,7 @@ def gemm_roofline(step_fn, dtype, cfg='c2'):
     torch.cuda.synchronize()
     by_tile = {}
     for rec in trace:
-        d = by_tile.setdefault((rec['tile'], rec['odt'], rec.get('fuse', False)), {'flops': 0.0, 'time': 0.0, 'hot': 0.0, 'launches': 0, 'grids': [], 'bytes': 0.0, 'recs': []})
+        d = by_tile.setdefault((rec['tile'], rec['odt'], rec.get('fuse', False), rec.get('trans', 0)), {'flops': 0.0, 'time': 0.0, 'hot': 0.0, 'launches': 0, 'grids': [], 'bytes': 0.0, 'recs': []})
         d['flops'] += rec['flops']; d['launches'] += 1; d['grids'].append(rec['wgs'] * 256); d['recs'].append(rec)
         esz, osz = (2 if rec['dt'] == 1 else 4), (4 if rec['odt'] == 0 else 2)
         d['bytes'] += sum((a.M * a.K + a.N * a.K) * esz + a.M * a.N * osz + (a.M * a.N * esz if a.residual else 0) for a in rec['arr'])
@@ -198,11 +198,12 @@ def gemm_roofline(step_fn, dtype, cfg='c2'):
                 d['hot'] += e0.elapsed_time(e1) * 1e-3 / 20
     dom = max(by_tile, key=lambda k: by_tile[k]['time'])
     d = by_tile[dom]
-    (bm, bn, nst), odt, fused = dom
+    (bm, bn, nst), odt, fused, trans = dom
     peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
-    sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d, %s,' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
-                                                       'float' if odt == 0 else 'unsigned short', bm, bn, nst, 'true' if fused else 'false')
+    sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d, %s, %d, 2, %d>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
+                                                                  'float' if odt == 0 else 'unsigned short', bm, bn, nst, 'true' if fused else 'false',
+                                                                  4 if bm == 256 else 2, trans)
     traffic, src = pmc_traffic(sig, d['grids'], cfg)
     prof_us, prof_src = profile_avg_us(sig, cfg)
     fpl = d['flops'] / d['launches']
@@ -212,12 +213,12 @@ def gemm_roofline(step_fn, dtype, cfg='c2'):
             'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
             'traffic_source': src, 'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
             'algorithmic_flops_per_launch': fpl,
-            'kernel': sig + ' ...>', 'ln_fused_epilogue': fused, 'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
+            'kernel': sig, 'ln_fused_epilogue': fused, 'operand_form': {0: 'NT', 1: 'TN (A stored [K,M])', 2: 'NN (dgrad)', 3: 'TN (wgrad)'}[trans], 'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
             'avg_launch_us_isolated': d['hot'] / d['launches'] * 1e6,
             'timing': 'HIP events around a graph of the variant\'s launches in step order, operands cold (as in the step)',
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
             'all_gemm_us_per_step': tot_t * 1e6,
-            'variants': {'%dx%dx%d/%s%s' % (k[0] + ('f32' if k[1] == 0 else 'bf16', '/ln-fused' if k[2] else '')): {'launches': v['launches'], 'us': v['time'] * 1e6, 'tflops': v['flops'] / v['time'] / 1e12}
+            'variants': {'%dx%dx%d/%s%s%s' % (k[0] + ('f32' if k[1] == 0 else 'bf16', '/ln-fused' if k[2] else '', {0: '', 1: '/tn', 2: '/nn-dgrad', 3: '/tn-wgrad'}[k[3]])): {'launches': v['launches'], 'us': v['time'] * 1e6, 'tflops': v['flops'] / v['time'] / 1e12}
                          for k, v in by_tile.items()}}
 
 

@@ -188,7 +188,7 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
         bm, bn, nt, nst = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst))
         keep = [t for p in problems for t in p if t is not None] + res + [fuse]
-        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value), 'fuse': bool(fuse) and any(f for f in fuse),
+        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value), 'fuse': bool(fuse) and any(f for f in fuse), 'trans': int(arr[0].trans),
                            'wgs': nt.value, 'flops': sum(2.0 * a.M * a.N * a.K for a in arr), 'keep': keep})
     return res
 
