@@ -114,6 +114,8 @@ SIGNATURES = {
     'dsrg_graph_update_embeds': (C.c_int, [C.POINTER(GraphState), _P, _P, _P, _P, _I, _P, _L, _I, _P, _I, _I, _I, _P]),
     'dsrg_graph_nav_inputs': (C.c_int, [C.POINTER(GraphState), C.POINTER(GraphNavOut), _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     'dsrg_action_tail_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'dsrg_ce_rows_fwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _I, _I, _P]),
+    'dsrg_ce_rows_bwd': (C.c_int, [_P, _I, _P, _L, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dsrg_igl_blend_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 

@@ -458,6 +458,59 @@ __global__ __launch_bounds__(64) void action_tail_kernel(const float* __restrict
   }
 }
 
+// ---- cross-entropy rows (the pre-training loss tails: F.cross_entropy(.., reduction='none') over the 30,522-word MLM
+// scores and the SAP logits, pretrain_cmt.py:160-167, 286-294).  One 256-thread workgroup per row.
+//   forward : ONE pass over the row with an online (max, sum exp) per thread, combined through LDS:
+//             lse_b, loss_b = lse_b - logit[b, target_b] (0 when the target is ignore_index / out of range);
+//   backward: dlogits[b, j] = g_b * (exp(logit[b, j] - lse_b) - [j == target_b])  (0 row when ignored), recomputed from the
+//             logits and lse: no log-softmax matrix is ever stored.
+__device__ __forceinline__ void ms_combine(float& m, float& s, float om, float os) {
+  const float nm = fmaxf(m, om);
+  if (nm == -INFINITY) { s = 0.f; return; }
+  s = s * __expf(m - nm) + os * __expf(om - nm);
+  m = nm;
+}
+__global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ targets,
+                                                          int64_t ignore, float* __restrict__ lse_rows, float* __restrict__ loss_rows, int N) {
+  __shared__ float sm[4], ss[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (size_t)b * ld;
+  float m = -INFINITY, s = 0.f;
+  for (int j = tid; j < N; j += 256) {
+    const float v = row[j];
+    if (v > m) { s = s * __expf(m - v) + 1.f; m = v; }      // exp(-inf - v) = 0 on the first finite value
+    else if (v > -INFINITY) s += __expf(v - m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ms_combine(m, s, __shfl_xor(m, o), __shfl_xor(s, o));
+  if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) ms_combine(m, s, sm[w], ss[w]);     // fixed order
+    const float lse = m + logf(s);
+    const int64_t t = targets[b];
+    const bool live = t != ignore && t >= 0 && t < N;
+    lse_rows[b] = lse;
+    loss_rows[b] = live ? lse - row[t] : 0.f;
+  }
+}
+template <typename OutT>
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ targets,
+                                                          int64_t ignore, const float* __restrict__ lse_rows, const float* __restrict__ g,
+                                                          OutT* __restrict__ dlogits, int ldd, int N) {
+  const int b = blockIdx.x;
+  const float* row = logits + (size_t)b * ld;
+  OutT* out = dlogits + (size_t)b * ldd;
+  const int64_t t = targets[b];
+  const bool live = t != ignore && t >= 0 && t < N;
+  const float lse = lse_rows[b], gb = live ? g[b] : 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float p = live ? __expf(row[j] - lse) - (j == (int)t ? 1.f : 0.f) : 0.f;
+    Elem<OutT>::st(out + j, gb * p);
+  }
+  for (int j = N + threadIdx.x; j < ldd; j += 256) Elem<OutT>::st(out + j, 0.f);     // padding columns of a wider buffer
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void igl_blend_kernel(const T* __restrict__ aug, const T* __restrict__ x, const float* __restrict__ wa,
                                                         const float* __restrict__ ba, const float* __restrict__ wo, const float* __restrict__ bo,
@@ -666,6 +719,27 @@ extern "C" int dsrg_igl_blend_fwd(const void* aug, const void* x, const float* w
   if (dtype == DSRG_F32) hipLaunchKernelGGL((igl_blend_kernel<float>), grid, block, 0, s, (const float*)aug, (const float*)x, wa, ba, wo, bo, (float*)out, M, H);
   else hipLaunchKernelGGL((igl_blend_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)aug, (const bf16_t*)x, wa, ba, wo, bo, (bf16_t*)out, M, H);
   DSRG_LAUNCH_CHECK("dsrg_igl_blend_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_ce_rows_fwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, float* lse_rows,
+                                float* loss_rows, int B, int N, void* stream) {
+  DSRG_CHECK(logits && targets && lse_rows && loss_rows && B >= 0 && N >= 1 && ld >= N, "dsrg_ce_rows_fwd: bad arguments");
+  if (B == 0) return DSRG_OK;
+  hipLaunchKernelGGL(ce_rows_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, ignore_index, lse_rows, loss_rows, N);
+  DSRG_LAUNCH_CHECK("dsrg_ce_rows_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_ce_rows_bwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, const float* lse_rows,
+                                const float* grad_rows, void* dlogits, int ldd, int out_dtype, int B, int N, void* stream) {
+  DSRG_CHECK(logits && targets && lse_rows && grad_rows && dlogits && B >= 0 && N >= 1 && ld >= N && ldd >= N, "dsrg_ce_rows_bwd: bad arguments");
+  DSRG_CHECK(ok_dtype(out_dtype), "dsrg_ce_rows_bwd: bad out_dtype %d", out_dtype);
+  if (B == 0) return DSRG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == DSRG_F32) hipLaunchKernelGGL((ce_rows_bwd_kernel<float>), dim3(B), dim3(256), 0, s, logits, ld, targets, ignore_index, lse_rows, grad_rows, (float*)dlogits, ldd, N);
+  else hipLaunchKernelGGL((ce_rows_bwd_kernel<bf16_t>), dim3(B), dim3(256), 0, s, logits, ld, targets, ignore_index, lse_rows, grad_rows, (bf16_t*)dlogits, ldd, N);
+  DSRG_LAUNCH_CHECK("dsrg_ce_rows_bwd");
   return DSRG_OK;
 }
 

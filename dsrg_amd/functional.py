@@ -713,6 +713,31 @@ class _ActionLossFn(torch.autograd.Function):
         return d * gl, None, None
 
 
+class _CERowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        loss, lse = K.ce_rows(logits, targets, ignore_index)
+        ctx.ignore = ignore_index
+        ctx.save_for_backward(logits, targets, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets, lse = ctx.saved_tensors
+        return K.ce_rows_bwd(logits, targets, lse, g, ctx.ignore), None, None
+
+
+def cross_entropy_rows(logits, targets, ignore_index=-100):
+    """F.cross_entropy(logits, targets, ignore_index=ignore_index, reduction='none') for fp32 [B,N] logits (-inf = masked):
+    one pass over each row in forward (dsrg_ce_rows_fwd), the gradient recomputed from the logits and the row log-sum-exp in
+    backward (dsrg_ce_rows_bwd); no log-softmax matrix (173 x 30,522 for the MLM head) is stored."""
+    lg = logits if logits.dtype == torch.float32 else logits.float()
+    lg = lg if lg.stride(-1) == 1 else lg.contiguous()
+    if torch.is_grad_enabled() and lg.requires_grad:
+        return _CERowsFn.apply(lg, targets.contiguous(), ignore_index)
+    return K.ce_rows(lg.detach(), targets.contiguous(), ignore_index)[0]
+
+
 def action_tail(nav_logits, targets=None, u=None, ignore_index=-100):
     """One kernel for what the rollout does with a step's logits: stop probability (softmax[:,0]), greedy action, entropy,
     optionally an inverse-CDF sample for the caller's uniforms `u`, and with `targets` the summed cross-entropy

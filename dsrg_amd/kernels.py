@@ -599,6 +599,31 @@ def action_tail(logits, targets=None, u=None, ignore_index=-100, want_grad=False
     return out
 
 
+def ce_rows(logits, targets, ignore_index=-100):
+    """fp32 logits [B,N] -> (loss_rows [B], lse_rows [B]) = F.cross_entropy(reduction='none') and the row log-sum-exp"""
+    lib = _lib.load()
+    _dev(logits)
+    if logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise _lib.DsrgHipError('ce_rows: logits must be fp32 [B,N] with contiguous rows')
+    B, N = logits.shape
+    if targets.dtype != torch.int64 or targets.shape != (B,) or not targets.is_contiguous():
+        raise _lib.DsrgHipError('ce_rows: targets must be contiguous int64 [B]')
+    loss, lse = torch.empty(B, device=logits.device), torch.empty(B, device=logits.device)
+    _lib.check(lib.dsrg_ce_rows_fwd(_p(logits), logits.stride(0), _p(targets), int(ignore_index), _p(lse), _p(loss), B, N, _stream()), 'dsrg_ce_rows_fwd')
+    return loss, lse
+
+
+def ce_rows_bwd(logits, targets, lse, grad_rows, ignore_index=-100, out_dtype=torch.float32):
+    """-> dlogits [B,N] (out_dtype) = grad_rows[:,None] * (softmax(logits) - onehot(targets))"""
+    lib = _lib.load()
+    B, N = logits.shape
+    g = grad_rows if (grad_rows.dtype == torch.float32 and grad_rows.is_contiguous()) else grad_rows.float().contiguous()
+    d = torch.empty(B, N, device=logits.device, dtype=out_dtype)
+    _lib.check(lib.dsrg_ce_rows_bwd(_p(logits), logits.stride(0), _p(targets), int(ignore_index), _p(lse), _p(g), _p(d), N, _dt(d), B, N, _stream()),
+               'dsrg_ce_rows_bwd')
+    return d
+
+
 # ----------------------------------------------------------------------------- backward of the row kernels
 def group_mean_bwd(dy, G):
     lib = _lib.load()

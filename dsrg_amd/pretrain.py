@@ -256,7 +256,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         h = Fn.layernorm(h, W['mlm.ln.g'], W['mlm.ln.b'], self.config.layer_norm_eps, out_dtype=cd)
         scores = Fn.linear(h, W['mlm.dec.w'], W['mlm.dec.b'], out_f32=True)
         if compute_loss:
-            return F.cross_entropy(scores, b['txt_labels'][sel], reduction='none')
+            return Fn.cross_entropy_rows(scores, b['txt_labels'][sel])
         return scores
 
     def _region_logits(self, W, key, x):
@@ -316,7 +316,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         _, v, last = self.bert.forward_backbone(b, return_gmap_embeds=False)
         obj_logits = self._og_logits(W, b, v, last)
         if compute_loss:
-            return F.cross_entropy(obj_logits, b['obj_labels'], reduction='none')
+            return Fn.cross_entropy_rows(obj_logits, b['obj_labels'])
         return obj_logits
 
     def forward_sap_og(self, b):   # pretrain_cmt.py:329-392
@@ -334,9 +334,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         gl, ll, fl = self._sap_logits(W, b, g, v, last)
         if not compute_loss:
             return gl, ll, fl, b['global_act_labels'], b['local_act_labels']
-        return F.cross_entropy(gl, b['global_act_labels'], reduction='none') \
-            + F.cross_entropy(ll, b['local_act_labels'], reduction='none') \
-            + F.cross_entropy(fl, b['global_act_labels'], reduction='none')
+        return Fn.cross_entropy_rows(gl, b['global_act_labels']) + Fn.cross_entropy_rows(ll, b['local_act_labels']) \
+            + Fn.cross_entropy_rows(fl, b['global_act_labels'])
 
     def _sap_logits(self, W, b, g, v, last):   # pretrain_cmt.py:248-285
         B, G, _ = g.shape

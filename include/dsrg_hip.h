@@ -223,6 +223,16 @@ int dsrg_action_tail_fwd(const float* logits, int ld, const int64_t* targets, in
                          float* stop_prob, int32_t* argmax, int32_t* sample, float* entropy, float* loss_rows,
                          float* dlogits, int B, int N, void* stream);
 
+/* Cross-entropy rows = F.cross_entropy(logits, targets, ignore_index, reduction='none') of the pre-training losses
+ * (PT/model/pretrain_cmt.py:160-167 MLM over the vocabulary, :286-294 the three SAP terms, :325 OG).  logits fp32 [B,N]
+ * (row stride ld, -inf = masked); fwd: lse_rows[b] = logsumexp, loss_rows[b] = lse - logits[b,target] (0 when the target is
+ * ignore_index or out of range), one pass over the row; bwd: dlogits[b,j] = grad_rows[b] * (softmax - onehot) recomputed
+ * from logits and lse_rows (0 row when ignored), written in out_dtype with row stride ldd (columns N..ldd-1 zeroed). */
+int dsrg_ce_rows_fwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, float* lse_rows,
+                     float* loss_rows, int B, int N, void* stream);
+int dsrg_ce_rows_bwd(const float* logits, int ld, const int64_t* targets, int64_t ignore_index, const float* lse_rows,
+                     const float* grad_rows, void* dlogits, int ldd, int out_dtype, int B, int N, void* stream);
+
 /* ---- device-resident graph map + navigation-input assembly ------------------------
  * Replaces GraphMap / FloydGraph (FT/models/graph_utils.py:42-148), the per-step graph / node-embedding updates of the
  * rollout (FT/r2r/agent.py:406-408, 434-451, 565-569) and the builders _nav_gmap_variable / _nav_vp_variable (:157-278).

@@ -813,3 +813,28 @@ def test_attention_packed_backward_matches_sliced(K, dtype, cross):
     a, b = Fn.split_cols(x, widths)
     (a.float() * 2).sum().backward()
     assert torch.equal(x.grad[..., :H], torch.full_like(x.grad[..., :H], 2.0)) and x.grad[..., H:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('B,N', [(173, 30522), (24, 37), (1, 1), (64, 257)])
+def test_cross_entropy_rows(K, B, N):
+    """functional.cross_entropy_rows (dsrg_ce_rows_fwd / _bwd) against F.cross_entropy(reduction='none') and its autograd:
+    -inf masked logits, ignored targets, per-row upstream gradients."""
+    from dsrg_amd import functional as Fn
+    torch.manual_seed(B + N)
+    lg0 = torch.randn(B, N, device='cuda') * 3
+    tg = torch.randint(0, N, (B,), device='cuda')
+    if N > 4:
+        lg0[:, 1::3] = -float('inf')
+        lg0[torch.arange(B, device='cuda'), tg] = torch.randn(B, device='cuda')       # the target itself is never masked
+        tg[::5] = -100
+    gup = torch.rand(B, device='cuda') + 0.1
+    a = lg0.clone().requires_grad_(True); b = lg0.clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(a, tg, reduction='none')
+    got = Fn.cross_entropy_rows(b, tg)
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    (want * gup).sum().backward(); (got * gup).sum().backward()
+    assert (a.grad - b.grad).abs().max().item() <= 2e-6
+    with torch.no_grad():
+        assert torch.equal(Fn.cross_entropy_rows(lg0, tg), got.detach())
+    d16 = K.ce_rows_bwd(lg0, tg, K.ce_rows(lg0, tg)[1], gup, out_dtype=torch.bfloat16)
+    assert (d16.float() - b.grad).abs().max().item() <= 8e-3
