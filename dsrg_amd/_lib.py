@@ -89,6 +89,8 @@ SIGNATURES = {
                                              _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_uint64, _I, _P]),
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     'dsrg_layernorm_fwd_grouped': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _P]),
+    'dsrg_layernorm_fwd_grouped_drop': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _F, C.c_uint64, _P]),
+    'dsrg_layernorm_bwd_drop': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _F, C.c_uint64, _I, _P]),
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
                                     _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),

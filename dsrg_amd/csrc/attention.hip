@@ -25,16 +25,8 @@ struct AttnArgs {
   unsigned long long seed;
 };
 
-// Dropout on the attention probabilities (vilmodel.py:115,150; nn.MultiheadAttention(dropout=)): the keep decision of
-// element (b, h, q, k) is a counter-based hash of (seed, flat index), so the backward recomputes the same mask and no
-// mask tensor exists.  Returns 1/(1-p) for a kept element, 0 for a dropped one.
-__device__ __forceinline__ float drop_keep(unsigned long long seed, size_t idx, float p, float inv_keep) {
-  unsigned long long z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
-}
+// Dropout on the attention probabilities (vilmodel.py:115,150; nn.MultiheadAttention(dropout=)): drop_keep() of common.h on
+// the flat index of element (b, h, q, k); the backward recomputes the same mask and no mask tensor exists.
 
 // up to DSRG_ATTN_MAX_GROUPS independent problems (same B, NH, mask mode, dtype) in one launch: blockIdx.x walks the
 // query blocks of problem 0, then problem 1, ...

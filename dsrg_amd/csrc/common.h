@@ -146,3 +146,15 @@ __device__ __forceinline__ void stage_wt(float* WT, const float* __restrict__ Wf
     }
   }
 }
+
+// Counter-based dropout: the keep decision of element `idx` of a tensor is a hash (splitmix64 finaliser) of (seed, idx), so a
+// backward kernel recomputes the mask and no mask tensor exists.  Returns inv_keep = 1/(1-p) for a kept element, 0 for a
+// dropped one.  Used on the attention probabilities (attention.hip) and on the hidden states in front of a residual
+// LayerNorm (rowops.hip / train.hip).
+__device__ __forceinline__ float drop_keep(unsigned long long seed, size_t idx, float p, float inv_keep) {
+  unsigned long long z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
+}

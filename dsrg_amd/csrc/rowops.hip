@@ -52,12 +52,16 @@ struct LnArgs {
   int blk_start[DSRG_MAX_GROUPS + 1];     // first workgroup of each problem (WPB rows per workgroup)
   int nprob, H;
   float eps;
+  // hidden-state dropout in front of the residual add (training): x is scaled by drop_keep(seed, (tag << 40) + row * H + col)
+  float p_drop, inv_keep;
+  unsigned long long seed;
+  int tag[DSRG_MAX_GROUPS];
 };
 
 // NV = float4 chunks per lane (ceil(H / 256)), a template parameter so that every load of the row - x, the residual,
 // gamma, beta - is issued up front without a per-lane condition: behind `if (c < H)` the compiler waited for each load
 // before issuing the next (six exposed latencies for a 768-wide row with residual).  Lanes past H load a clamped column.
-template <typename TI, typename TO, int NV>
+template <typename TI, typename TO, int NV, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
   int g = 0;
@@ -83,6 +87,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     const int c = min((i * 64 + lane) * 4, H - 4);
     gm[i] = *reinterpret_cast<const float4*>(P.gamma + c);
     bt[i] = *reinterpret_cast<const float4*>(P.beta + c);
+  }
+  if constexpr (DROP) {       // dropout(x) before the residual add (BertSelfOutput / BertOutput, vilmodel.py:173-177, 213-217)
+    const size_t base = ((size_t)a.tag[g] << 40) + (size_t)row * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const size_t c = base + min((i * 64 + lane) * 4, H - 4);
+      v[i].x *= drop_keep(a.seed, c, a.p_drop, a.inv_keep); v[i].y *= drop_keep(a.seed, c + 1, a.p_drop, a.inv_keep);
+      v[i].z *= drop_keep(a.seed, c + 2, a.p_drop, a.inv_keep); v[i].w *= drop_keep(a.seed, c + 3, a.p_drop, a.inv_keep);
+    }
   }
   if (res) {
 #pragma unroll
@@ -548,8 +561,9 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
-                                          int out_dtype, void* stream) {
+static int layernorm_fwd_impl(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
+                              int out_dtype, float p_drop, unsigned long long seed, void* stream) {
+  DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_layernorm_fwd: p_drop=%g out of [0,1)", (double)p_drop);
   DSRG_CHECK(problems && nproblems >= 1 && nproblems <= DSRG_MAX_GROUPS, "dsrg_layernorm_fwd: nproblems=%d out of [1,%d]", nproblems,
              DSRG_MAX_GROUPS);
   DSRG_CHECK(ok_dtype(in_dtype) && ok_dtype(out_dtype), "dsrg_layernorm_fwd: bad dtype");
@@ -557,6 +571,7 @@ extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_layernorm_fwd: H=%d must be a multiple of 64 and <= 1024", H);
   LnArgs a;
   a.nprob = 0; a.H = H; a.eps = eps;
+  a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
   int blocks = 0;
   for (int i = 0; i < nproblems; ++i) {
     const dsrg_ln_problem_t& p = problems[i];
@@ -569,6 +584,7 @@ extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int
                    (in_dtype == DSRG_BF16 || al16(p.x)) && (out_dtype == DSRG_BF16 || (al16(p.out) && al16(p.residual))),
                "dsrg_layernorm_fwd: problem %d has a misaligned pointer", i);
     a.blk_start[a.nprob] = blocks;
+    a.tag[a.nprob] = i;
     a.p[a.nprob++] = p;
     blocks += (p.M + WPB - 1) / WPB;
   }
@@ -578,7 +594,11 @@ extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int
   dim3 grid(blocks), block(256);
 #define DSRG_LN_LAUNCH(NV_)                                                                                              \
   do {                                                                                                                  \
-    if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float, NV_>), grid, block, 0, s, a);         \
+    if (p_drop > 0.f) {                                                                                                 \
+      if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float, NV_, true>), grid, block, 0, s, a);      \
+      else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t, NV_, true>), grid, block, 0, s, a); \
+      else hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t, NV_, true>), grid, block, 0, s, a);                          \
+    } else if (out_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, float, NV_>), grid, block, 0, s, a);  \
     else if (in_dtype == DSRG_F32) hipLaunchKernelGGL((layernorm_kernel<float, bf16_t, NV_>), grid, block, 0, s, a);    \
     else hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t, NV_>), grid, block, 0, s, a);                             \
   } while (0)
@@ -591,6 +611,16 @@ extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int
 #undef DSRG_LN_LAUNCH
   DSRG_LAUNCH_CHECK("dsrg_layernorm_fwd");
   return DSRG_OK;
+}
+
+extern "C" int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
+                                          int out_dtype, void* stream) {
+  return layernorm_fwd_impl(problems, nproblems, H, eps, in_dtype, out_dtype, 0.f, 0, stream);
+}
+
+extern "C" int dsrg_layernorm_fwd_grouped_drop(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
+                                               int out_dtype, float p_drop, uint64_t seed, void* stream) {
+  return layernorm_fwd_impl(problems, nproblems, H, eps, in_dtype, out_dtype, p_drop, seed, stream);
 }
 
 extern "C" int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta,

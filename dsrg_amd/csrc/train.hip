@@ -133,11 +133,15 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const
 // One wave per row, each block walks a strip of rows and keeps its dgamma/dbeta partials in registers, then one
 // atomic per column per block.
 constexpr int LNB_MAXV = 4;
-template <typename TX, typename T>
+// DROP: the forward ran  z = dropout(x) + res  (dsrg_layernorm_fwd_grouped_drop): the mask is recomputed from (seed, tag, row,
+// col); dz is the gradient of the residual, dzd = dz * keep / (1 - p) the gradient of x (the dense output in front of it).
+struct LnDrop { float p, inv_keep; unsigned long long seed; int tag; };
+template <typename TX, typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, int ldx, const T* __restrict__ res, int ldr,
                                                             const float* __restrict__ gamma, const T* __restrict__ dy, int lddy,
                                                             T* __restrict__ dz, int lddz, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int H, float eps, int rows_per_block) {
+                                                            int M, int H, float eps, int rows_per_block, LnDrop dr = LnDrop{},
+                                                            T* __restrict__ dzd = nullptr, int lddzd = 0) {
   __shared__ float red[2][4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (H + 255) / 256;
@@ -150,13 +154,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     gm[i] = (i < nv && c < H) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int row = m0 + wave; row < m1; row += 4) {
-    float4 z[LNB_MAXV], g[LNB_MAXV];
+    float4 z[LNB_MAXV], g[LNB_MAXV], kp[DROP ? LNB_MAXV : 1];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
         z[i] = ld4(x + (size_t)row * ldx + c);
+        if constexpr (DROP) {
+          const size_t e = ((size_t)dr.tag << 40) + (size_t)row * H + c;
+          kp[i] = make_float4(drop_keep(dr.seed, e, dr.p, dr.inv_keep), drop_keep(dr.seed, e + 1, dr.p, dr.inv_keep),
+                              drop_keep(dr.seed, e + 2, dr.p, dr.inv_keep), drop_keep(dr.seed, e + 3, dr.p, dr.inv_keep));
+          z[i].x *= kp[i].x; z[i].y *= kp[i].y; z[i].z *= kp[i].z; z[i].w *= kp[i].w;
+        }
         if (res) { const float4 r = ld4(res + (size_t)row * ldr + c); z[i].x += r.x; z[i].y += r.y; z[i].z += r.z; z[i].w += r.w; }
         g[i] = ld4(dy + (size_t)row * lddy + c);
         s += z[i].x + z[i].y + z[i].z + z[i].w;
@@ -190,9 +200,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (i < nv && c < H)
-        st4(dz + (size_t)row * lddz + c, make_float4(rstd * (g[i].x - mg - z[i].x * mgz), rstd * (g[i].y - mg - z[i].y * mgz),
-                                                      rstd * (g[i].z - mg - z[i].z * mgz), rstd * (g[i].w - mg - z[i].w * mgz)));
+      if (i < nv && c < H) {
+        const float4 d = make_float4(rstd * (g[i].x - mg - z[i].x * mgz), rstd * (g[i].y - mg - z[i].y * mgz),
+                                     rstd * (g[i].z - mg - z[i].z * mgz), rstd * (g[i].w - mg - z[i].w * mgz));
+        if (dz) st4(dz + (size_t)row * lddz + c, d);
+        if constexpr (DROP) st4(dzd + (size_t)row * lddzd + c, make_float4(d.x * kp[i].x, d.y * kp[i].y, d.z * kp[i].z, d.w * kp[i].w));
+      }
     }
   }
   // combine the 4 waves' partials, one atomic per column
@@ -288,22 +301,39 @@ extern "C" int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, 
   return DSRG_OK;
 }
 
-extern "C" int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
-                                  void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps, int in_dtype, int dtype,
-                                  void* stream) {
-  DSRG_CHECK(x && gamma && dy && dz && dgamma && dbeta && okdt(in_dtype) && okdt(dtype), "dsrg_layernorm_bwd: bad pointer or dtype");
+static int layernorm_bwd_impl(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
+                              void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps, int in_dtype,
+                              int dtype, float p_drop, unsigned long long seed, int tag, void* stream) {
+  DSRG_CHECK(x && gamma && dy && dgamma && dbeta && okdt(in_dtype) && okdt(dtype), "dsrg_layernorm_bwd: bad pointer or dtype");
   DSRG_CHECK(in_dtype == DSRG_F32 || in_dtype == dtype, "dsrg_layernorm_bwd: in_dtype must be f32 or equal dtype");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddz % 4 == 0 && (!residual || ldr % 4 == 0), "dsrg_layernorm_bwd: bad H / leading dims");
+  DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f && tag >= 0 && tag < DSRG_MAX_GROUPS, "dsrg_layernorm_bwd: p_drop=%g out of [0,1) or bad tag %d", (double)p_drop, tag);
+  const bool drop = p_drop > 0.f;
+  DSRG_CHECK(drop ? (dzd != nullptr && lddzd >= H && lddzd % 4 == 0) : dz != nullptr, "dsrg_layernorm_bwd: missing gradient output");
   if (M <= 0) return DSRG_OK;
   const int rpb = 16;
   dim3 grid((M + rpb - 1) / rpb), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == DSRG_F32 && dtype == DSRG_F32)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float, float>), grid, block, 0, s, (const float*)x, ldx, (const float*)residual, ldr, gamma, (const float*)dy, lddy, (float*)dz, lddz, dgamma, dbeta, M, H, eps, rpb);
-  else if (in_dtype == DSRG_F32)
-    hipLaunchKernelGGL((layernorm_bwd_kernel<float, bf16_t>), grid, block, 0, s, (const float*)x, ldx, (const bf16_t*)residual, ldr, gamma, (const bf16_t*)dy, lddy, (bf16_t*)dz, lddz, dgamma, dbeta, M, H, eps, rpb);
-  else
-    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, gamma, (const bf16_t*)dy, lddy, (bf16_t*)dz, lddz, dgamma, dbeta, M, H, eps, rpb);
+  const LnDrop dr{p_drop, 1.0f / (1.0f - p_drop), seed, tag};
+#define DSRG_LNB(TX_, T_, DROP_)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TX_, T_, DROP_>), grid, block, 0, s, (const TX_*)x, ldx, (const T_*)residual, ldr, gamma, \
+                     (const T_*)dy, lddy, (T_*)dz, lddz, dgamma, dbeta, M, H, eps, rpb, dr, (T_*)dzd, lddzd)
+  if (in_dtype == DSRG_F32 && dtype == DSRG_F32) { if (drop) DSRG_LNB(float, float, true); else DSRG_LNB(float, float, false); }
+  else if (in_dtype == DSRG_F32) { if (drop) DSRG_LNB(float, bf16_t, true); else DSRG_LNB(float, bf16_t, false); }
+  else { if (drop) DSRG_LNB(bf16_t, bf16_t, true); else DSRG_LNB(bf16_t, bf16_t, false); }
+#undef DSRG_LNB
   DSRG_LAUNCH_CHECK("dsrg_layernorm_bwd");
   return DSRG_OK;
+}
+
+extern "C" int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
+                                  void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps, int in_dtype, int dtype,
+                                  void* stream) {
+  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, nullptr, 0, dgamma, dbeta, M, H, eps, in_dtype, dtype, 0.f, 0, 0, stream);
+}
+
+extern "C" int dsrg_layernorm_bwd_drop(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
+                                       void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps,
+                                       int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream) {
+  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, dzd, lddzd, dgamma, dbeta, M, H, eps, in_dtype, dtype, p_drop, seed, tag, stream);
 }

@@ -301,6 +301,9 @@ def linear(x, w, b=None, act=ACT_NONE, residual=None, out_f32=False):
 
 
 # ----------------------------------------------------------------------------- dense (+dropout) + residual + LayerNorm
+FUSED_HIDDEN_DROPOUT = __import__('os').environ.get('DSRG_FUSED_HIDDEN_DROPOUT', '1') == '1'    # 0: torch.native_dropout + mask tensors (A/B)
+
+
 class _LinearLNFn(torch.autograd.Function):
     """y_i = LN(drop(x_i W_i^T + b_i) + r_i) * gamma_i + beta_i, grouped (BertSelfOutput / BertOutput and every
     Linear->LayerNorm pair).  The fp32 pre-LN sum is kept for the backward; backward = LN-backward kernel, then the
@@ -312,7 +315,14 @@ class _LinearLNFn(torch.autograd.Function):
         ctx.n, ctx.eps = n, eps
         ctx.shapes = [p[0].shape for p in probs]
         with torch.no_grad():
-            if p_drop > 0:
+            masks = [None] * n
+            ctx.seed = 0
+            if p_drop > 0 and FUSED_HIDDEN_DROPOUT:
+                # dropout inside the LayerNorm kernel (counter-based mask, recomputed in backward): z stays the un-dropped dense output
+                ctx.seed = dropout_seed()
+                zs = K.gemm([(p[0], p[1], p[2], None) for p in probs], ACT_NONE, True)
+                ys = K.layernorm_grouped([(z, p[4], p[5], p[3]) for z, p in zip(zs, probs)], eps, probs[0][1].dtype, p_drop, ctx.seed)
+            elif p_drop > 0:
                 zs = K.gemm([(p[0], p[1], p[2], None) for p in probs], ACT_NONE, True)
                 masks = []
                 for i, z in enumerate(zs):
@@ -320,10 +330,11 @@ class _LinearLNFn(torch.autograd.Function):
                     masks.append(m)
                 ys = K.layernorm_grouped([(z, p[4], p[5], p[3]) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
             else:
-                masks = [None] * n
                 zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in probs], ACT_NONE, True)
                 ys = K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, probs)], eps, probs[0][1].dtype)
         ctx.drop = p_drop > 0
+        ctx.p_drop = p_drop
+        ctx.fused_drop = p_drop > 0 and FUSED_HIDDEN_DROPOUT
         ctx.scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         ctx.hasr = [p[3] is not None for p in probs]
         ctx.hasb = [p[2] is not None for p in probs]
@@ -340,14 +351,18 @@ class _LinearLNFn(torch.autograd.Function):
         for i in range(ctx.n):
             x, w, gamma, z = sv.pop(0), sv.pop(0), sv.pop(0), sv.pop(0)
             r = sv.pop(0) if (ctx.drop and ctx.hasr[i]) else None
-            m = sv.pop(0) if ctx.drop else None
+            m = sv.pop(0) if (ctx.drop and not ctx.fused_drop) else None
             dy = dys[i]
             if dy is None:
                 items.append(None); keep.append(None)
                 continue
             dy = dy if dy.dtype == w.dtype else dy.to(w.dtype)
-            dz, dg, dbt = K.layernorm_bwd(z, r, gamma, dy, ctx.eps)
-            dlin = dz if m is None else torch.ops.aten.native_dropout_backward(dz, m, ctx.scale)
+            if ctx.fused_drop:
+                dz, dlin, dg, dbt = K.layernorm_bwd(z, r, gamma, dy, ctx.eps, ctx.p_drop, ctx.seed, i,
+                                                    want_dz=ctx.hasr[i] and ctx.needs_input_grad[6 + 6 * i])
+            else:
+                dz, dg, dbt = K.layernorm_bwd(z, r, gamma, dy, ctx.eps)
+                dlin = dz if m is None else torch.ops.aten.native_dropout_backward(dz, m, ctx.scale)
             keep.append((dz, dg, dbt, dlin))
             items.append((_as2d(x), w, _as2d(dlin), ctx.needs_input_grad[3 + 6 * i], ctx.needs_input_grad[4 + 6 * i],
                           ctx.hasb[i] and ctx.needs_input_grad[5 + 6 * i]))

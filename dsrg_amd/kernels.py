@@ -344,8 +344,10 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
     return out
 
 
-def layernorm_grouped(problems, eps, out_dtype=None):
-    """problems: list of (x, gamma, beta, residual|None) with one H and one input dtype -> list of outputs, ONE launch."""
+def layernorm_grouped(problems, eps, out_dtype=None, p_drop=0.0, seed=0):
+    """problems: list of (x, gamma, beta, residual|None) with one H and one input dtype -> list of outputs, ONE launch.
+    p_drop > 0: out = LN(dropout(x) + residual) with the counter-based mask of (seed, problem index, row, col)
+    (dsrg_layernorm_fwd_grouped_drop; layernorm_bwd recomputes it)."""
     lib = _lib.load()
     n = len(problems)
     if not 1 <= n <= _lib.MAX_GROUPS:
@@ -364,6 +366,10 @@ def layernorm_grouped(problems, eps, out_dtype=None):
         outs.append(out)
         arr[i].x, arr[i].residual, arr[i].gamma, arr[i].beta, arr[i].out = _p(x), _p(r), _p(g), _p(b), _p(out)
         arr[i].M, arr[i].ldx, arr[i].ldr, arr[i].ldo = M, ldx, (_rows(r)[1] if r is not None else 0), _rows(out)[1]
+    if p_drop > 0.0:
+        _lib.check(lib.dsrg_layernorm_fwd_grouped_drop(arr, n, H, float(eps), _dt(x0), _dt(outs[0]), float(p_drop), int(seed), _stream()),
+                   'dsrg_layernorm_fwd_grouped_drop')
+        return outs
     _lib.check(lib.dsrg_layernorm_fwd_grouped(arr, n, H, float(eps), _dt(x0), _dt(outs[0]), _stream()), 'dsrg_layernorm_fwd_grouped')
     return outs
 
@@ -557,17 +563,26 @@ def act_bwd(z, dy, act):
     return dz
 
 
-def layernorm_bwd(x, residual, gamma, dy, eps):
-    """returns dz (dtype of dy), dgamma, dbeta (fp32)"""
+def layernorm_bwd(x, residual, gamma, dy, eps, p_drop=0.0, seed=0, tag=0, want_dz=True):
+    """returns dz (dtype of dy), dgamma, dbeta (fp32).  p_drop > 0 (the forward was layernorm_grouped(.., p_drop, seed) and x
+    was problem `tag` of it): returns (dz | None, dzd, dgamma, dbeta) - dz the residual's gradient (skipped when not want_dz),
+    dzd = dz * keep / (1 - p) the gradient of x."""
     lib = _lib.load()
     _dev(x)
     M, ldx = _rows(x)
     H = x.shape[-1]
     dy = rows_ok(dy)
-    dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
     dgb = zeros_f32((2, H), x.device)
     dg, db = dgb[0], dgb[1]
     ldr = _rows(residual)[1] if residual is not None else 0
+    if p_drop > 0.0:
+        dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype) if want_dz else None
+        dzd = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
+        _lib.check(lib.dsrg_layernorm_bwd_drop(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dzd)[1], _p(dzd),
+                                               _rows(dzd)[1], _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), float(p_drop), int(seed), int(tag),
+                                               _stream()), 'dsrg_layernorm_bwd_drop')
+        return dz, dzd, dg, db
+    dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
     _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
                                       _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')
     return dz, dg, db

@@ -414,6 +414,17 @@ int dsrg_segment_wsum(const void* in0, int ld0, int n0, const void* in1, int ld1
 int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy,
                        int lddy, void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps,
                        int in_dtype, int dtype, void* stream);
+/* Hidden-state dropout fused into the residual LayerNorm (training; BertSelfOutput / BertOutput, FT/vilmodel.py:173-177,
+ * 213-217: LayerNorm(dropout(dense(h)) + input)).  The keep decision of element (problem tag, row, col) is a counter-based
+ * hash of (seed, (tag << 40) + row * H + col) - tag = the problem's index in the grouped forward call - so no mask tensor is
+ * stored and the backward recomputes it from the SAME x (the un-dropped dense output):
+ *   fwd: out = LN(x * keep / (1 - p) + residual);   bwd: dz = dLN (the residual's gradient, may be NULL), dzd = dz * keep / (1 - p)
+ *   (the dense output's gradient).  p_drop = 0 is dsrg_layernorm_fwd_grouped / dsrg_layernorm_bwd. */
+int dsrg_layernorm_fwd_grouped_drop(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
+                                    int out_dtype, float p_drop, uint64_t seed, void* stream);
+int dsrg_layernorm_bwd_drop(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
+                            void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps,
+                            int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream);
 
 #ifdef __cplusplus
 }

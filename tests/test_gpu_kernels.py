@@ -710,10 +710,10 @@ def test_segment_wsum(dtype):
         assert (mine - t.grad.float()).abs().max().item() <= tol * max(1.0, t.grad.abs().max().item())
 
 
-def _keep_mask(seed, B, nh, Nq, Nk, p):
-    """numpy restatement of drop_keep() (attention.hip): splitmix64 finaliser of seed + (idx+1)*golden, top 24 bits -> u"""
+def _keep_mask(seed, B, nh, Nq, Nk, p, offset=0):
+    """numpy restatement of drop_keep() (common.h): splitmix64 finaliser of seed + (idx+1)*golden, top 24 bits -> u"""
     import numpy as np
-    idx = np.arange(B * nh * Nq * Nk, dtype=np.uint64)
+    idx = np.arange(B * nh * Nq * Nk, dtype=np.uint64) + np.uint64(offset)
     with np.errstate(over='ignore'):
         z = np.uint64(seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
@@ -838,3 +838,49 @@ def test_cross_entropy_rows(K, B, N):
         assert torch.equal(Fn.cross_entropy_rows(lg0, tg), got.detach())
     d16 = K.ce_rows_bwd(lg0, tg, K.ce_rows(lg0, tg)[1], gup, out_dtype=torch.bfloat16)
     assert (d16.float() - b.grad).abs().max().item() <= 8e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,H', [(1920, 768), (37, 128), (300, 1024)])
+def test_linear_ln_fused_hidden_dropout(K, dtype, M, H):
+    """LayerNorm(dropout(dense(h)) + input) with the dropout inside the LayerNorm kernels (dsrg_layernorm_fwd_grouped_drop /
+    dsrg_layernorm_bwd_drop): forward and every gradient against torch with the SAME keep mask (numpy restatement of the
+    counter hash; problem 1 of a grouped call uses index offset 1 << 40)."""
+    from dsrg_amd import functional as Fn
+    p, eps, Kin = 0.1, 1e-12, 256
+    torch.manual_seed(7)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device='cuda') * sc)
+    xs = [mk(M, Kin).to(dtype), mk(M // 2 + 1, Kin).to(dtype)]
+    ws = [mk(H, Kin, sc=0.05).to(dtype) for _ in range(2)]
+    bs = [mk(H, sc=0.1) for _ in range(2)]
+    rs = [mk(x.shape[0], H).to(dtype) for x in xs]
+    gs = [1 + mk(H, sc=0.1) for _ in range(2)]
+    bt = [mk(H, sc=0.1) for _ in range(2)]
+    leaves = [t.clone().requires_grad_(True) for t in xs + ws + bs + rs + gs + bt]
+    X, W, Bv, R, G, Bt = leaves[0:2], leaves[2:4], leaves[4:6], leaves[6:8], leaves[8:10], leaves[10:12]
+    seed = 123456789
+    orig = Fn.dropout_seed
+    Fn.dropout_seed = lambda: seed
+    try:
+        ys = Fn.linear_ln_grouped([(X[j], W[j], Bv[j], R[j], G[j], Bt[j]) for j in range(2)], eps, p)
+    finally:
+        Fn.dropout_seed = orig
+    gos = [mk(*y.shape).to(dtype) for y in ys]
+    torch.autograd.backward(ys, gos)
+    got = [t.grad.clone() for t in leaves]
+    # reference: same arithmetic in fp32 torch with the same mask (the dense output is fp32 in the kernel path too)
+    ref_leaves = [t.detach().float().clone().requires_grad_(True) for t in leaves]
+    X2, W2, B2, R2, G2, Bt2 = ref_leaves[0:2], ref_leaves[2:4], ref_leaves[4:6], ref_leaves[6:8], ref_leaves[8:10], ref_leaves[10:12]
+    outs = []
+    for j in range(2):
+        Mj = X2[j].shape[0]
+        keep = _keep_mask(seed, 1, 1, Mj, H, p, offset=j << 40)[0, 0].float() / (1 - p)
+        z = X2[j] @ W2[j].T + B2[j]
+        outs.append(torch.nn.functional.layer_norm(z * keep + R2[j], (H,), G2[j], Bt2[j], eps))
+    torch.autograd.backward(outs, [g.float() for g in gos])
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+    for j in range(2):
+        assert (ys[j].float() - outs[j]).abs().max().item() <= tol * max(1.0, outs[j].abs().max().item())
+    for a, b, name in zip(got, [t.grad for t in ref_leaves], ['x0', 'x1', 'w0', 'w1', 'b0', 'b1', 'r0', 'r1', 'g0', 'g1', 'bt0', 'bt1']):
+        sc = max(1.0, b.abs().max().item())
+        assert (a.float() - b).abs().max().item() <= (5e-4 if dtype == torch.float32 else 6e-2) * sc, name
