@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HeadTailProblem(C.Structure):
@@ -33,7 +33,7 @@ class GemmProblem(C.Structure):
                 ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32),
                 ('a_stats', C.c_void_p), ('a_c1', C.c_void_p), ('r_stats', C.c_void_p), ('r_gamma', C.c_void_p),
                 ('r_beta', C.c_void_p), ('stats_out', C.c_void_p), ('a_np', C.c_int32), ('r_np', C.c_int32),
-                ('ln_eps', C.c_float), ('trans', C.c_int32), ('a_colsum', C.c_void_p)]
+                ('ln_eps', C.c_float), ('trans', C.c_int32), ('a_colsum', C.c_void_p), ('c_pre', C.c_void_p), ('ldcp', C.c_int32), ('res_act', C.c_int32)]
 
 
 class AttnProblem(C.Structure):

@@ -158,3 +158,13 @@ __device__ __forceinline__ float drop_keep(unsigned long long seed, size_t idx, 
   z ^= z >> 31;
   return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
 }
+
+// d act(z) / dz for DSRG_ACT_* (erf-GELU of FT/vilmodel.py:30-31, ReLU, tanh)
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case DSRG_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+    case DSRG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case DSRG_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+    default: return 1.f;
+  }
+}

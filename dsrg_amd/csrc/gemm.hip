@@ -128,6 +128,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   const int oc = tid % CPR, orow0 = tid / CPR;
   const int n = n0 + oc * CW;
   const bool vec = (n + CW - 1 < N) && (P.ldc % CW == 0) && (Rp == nullptr || (P.ldr % CW == 0 && ((uintptr_t)Rp & 15) == 0));
+  // training forward: the pre-activation (accumulator + bias) also leaves, in the input dtype, for the backward (c_pre);
+  // training backward: res_act > 0 multiplies by act'(residual) instead of adding the residual (dX = (dY.W) * act'(z))
+  T* __restrict__ Cpre = reinterpret_cast<T*>(P.c_pre);
+  const int res_act = P.res_act;
   float bv[CW];
 #pragma unroll
   for (int e = 0; e < CW; ++e) bv[e] = 0.f;
@@ -521,9 +525,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
             if constexpr (FUSE) {
               if (P.a_stats) x = msa.y * (x - msa.x * c1v[4 * h + e]);
             }
-            v[4 * h + e] = apply_act<sizeof(OutT) == 2>(x + bv[4 * h + e], act);
+            v[4 * h + e] = x + bv[4 * h + e];
           }
         }
+        if (Cpre) {                          // host-checked: whole vectors only (N, ldcp multiples of 8, 16-byte aligned)
+          if (n + CW - 1 < N) {
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+              for (int h = 0; h < CW / 4; ++h) {
+                uint2 u;
+                u.x = (uint32_t)f2bf(v[4 * h]) | ((uint32_t)f2bf(v[4 * h + 1]) << 16);
+                u.y = (uint32_t)f2bf(v[4 * h + 2]) | ((uint32_t)f2bf(v[4 * h + 3]) << 16);
+                *reinterpret_cast<uint2*>(Cpre + (size_t)m * P.ldcp + n + 4 * h) = u;
+              }
+            } else {
+#pragma unroll
+              for (int h = 0; h < CW / 4; ++h) st4(Cpre + (size_t)m * P.ldcp + n + 4 * h, make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]));
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = apply_act<sizeof(OutT) == 2>(v[e], act);
         if (vec) {
           if (Rp) {
             RawRes raw;
@@ -543,8 +565,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
                 for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - msr.x) * msr.y * rgv[e] + rbv[e];
               }
             }
+            if (res_act > 0) {
 #pragma unroll
-            for (int e = 0; e < CW; ++e) v[e] += rv[e];
+              for (int e = 0; e < CW; ++e) v[e] *= act_grad(rv[e], res_act);
+            } else {
+#pragma unroll
+              for (int e = 0; e < CW; ++e) v[e] += rv[e];
+            }
           }
           if constexpr (FUSE) {
             if (P.stats_out) {        // partial (sum, sum of squares) of this row over the tile's BN columns, from the fp32 values
@@ -570,7 +597,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
         } else {
           for (int e = 0; e < CW && n + e < N; ++e) {
             float x = v[e];
-            if (Rp) x += Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
+            if (Rp) {
+              const float rr = Elem<T>::ld(Rp + (size_t)m * P.ldr + n + e);
+              x = res_act > 0 ? x * act_grad(rr, res_act) : x + rr;
+            }
             Elem<OutT>::st(C + (size_t)m * P.ldc + n + e, x);
           }
         }
@@ -764,6 +794,10 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
     DSRG_CHECK(p.A && p.W && p.C, "dsrg_gemm_nt: problem %d has a null A/W/C", i);
     DSRG_CHECK(p.K % bk == 0 || p.trans == 3, "dsrg_gemm_nt: problem %d K=%d must be a multiple of %d (any K only with trans = 3)", i, p.K, bk);
     DSRG_CHECK(!p.a_colsum || (p.trans & 1), "dsrg_gemm_nt: problem %d: a_colsum needs a transposed A (trans bit 0)", i);
+    DSRG_CHECK(!p.c_pre || (p.N % 8 == 0 && p.ldcp % 8 == 0 && p.ldcp >= p.N && ((uintptr_t)p.c_pre & 15) == 0 && !p.a_stats && !p.r_stats && !p.stats_out),
+               "dsrg_gemm_nt: problem %d: c_pre needs N and ldcp multiples of 8, a 16-byte aligned pointer and no LayerNorm fusion", i);
+    DSRG_CHECK(p.res_act >= DSRG_ACT_NONE && p.res_act <= DSRG_ACT_TANH && (p.res_act == DSRG_ACT_NONE || (p.residual && !p.r_stats)),
+               "dsrg_gemm_nt: problem %d: res_act=%d needs a residual (the pre-activation) and no r_stats", i, p.res_act);
     DSRG_CHECK(p.trans >= 0 && p.trans <= 3 && p.trans == problems[0].trans, "dsrg_gemm_nt: problem %d: trans=%d must be 0..3 and the same for the whole group", i, p.trans);
     DSRG_CHECK(p.trans == 0 || (dtype == DSRG_BF16 && !p.a_stats && !p.r_stats && !p.stats_out && fbm <= 0),
                "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion or a pinned tile", i);

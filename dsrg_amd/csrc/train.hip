@@ -104,14 +104,6 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
     default: return z;
   }
 }
-__device__ __forceinline__ float act_grad(float z, int act) {
-  switch (act) {
-    case DSRG_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
-    case DSRG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-    case DSRG_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
-    default: return 1.f;
-  }
-}
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const T* __restrict__ dy, T* __restrict__ out, size_t n4, int act) {

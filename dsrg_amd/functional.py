@@ -151,7 +151,9 @@ def _lies_ok(t):
 
 
 def _gemm_grads(items):
-    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw, need_db) -> (dx list, dw list, db list).
+    """items: list of (x2d, w, dy2d (compute dtype), need_dx, need_dw, need_db[, z2d, act]) -> (dx list, dw list, db list).
+    With (z2d, act) the dgrad leaves as dX * act'(z) (the GEMM epilogue's res_act: the activation backward of the layer
+    below costs no kernel).
     bf16 with friendly shapes (the transformer layers): dX = dY.W and dW = dY^T.X run on dY, W and X AS THEY LIE
     (dsrg_gemm_problem_t::trans = 2 / 3, ds_read_b64_tr_b16 fragments): one grouped launch for the dgrads, one for the wgrads
     (any row count: the partial last K-step is zero-filled on chip), no transposed copies; db = column sums of dY out of the
@@ -162,9 +164,12 @@ def _gemm_grads(items):
     dball = K.zeros_f32((nb,), items[0][2].device) if nb else None
     dxp, dwp, dbs, o = [], [], [], 0
     fdx, fdw, fdb = [], [], []                 # problems on operands as they lie (fdb: where a wgrad's column sums of dY go)
+    fra, tra = [], []                          # res_act of the dgrad problems (fast / transposed-copy path)
     tr = []                                    # every transpose of this call: one grouped launch
     slots = []                                 # per item: where its dx / dw come from
-    for x, w, dy, ndx, ndw, ndb in items:
+    for it in items:
+        x, w, dy, ndx, ndw, ndb = it[:6]
+        zr, ract = (it[6], it[7]) if len(it) > 6 else (None, 0)
         N, Kd = w.shape
         M = dy.shape[0]
         db = None
@@ -174,11 +179,11 @@ def _gemm_grads(items):
         sx = sw = None
         if ndx:
             if lies and N % 64 == 0:
-                sx = ('f', len(fdx)); fdx.append((dy, w, None, None))                    # [M,N] x ([N,K] stored [K',N'])
+                sx = ('f', len(fdx)); fdx.append((dy, w, None, zr)); fra.append(ract)    # [M,N] x ([N,K] stored [K',N'])
             else:
                 Np = (N + 63) // 64 * 64
                 dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
-                sx = ('t', len(dxp)); dxp.append([dyp, len(tr), None, None]); tr.append((w, None))   # [M,Np] x [K,Np]^T
+                sx = ('t', len(dxp)); dxp.append([dyp, len(tr), None, zr]); tra.append(ract); tr.append((w, None))   # [M,Np] x [K,Np]^T
         if ndw:
             if lies and _lies_ok(x):
                 sw = ('f', len(fdw)); fdw.append((dy, x, None, None)); fdb.append(db)    # dY [M,N] = [K',M'], X [M,K] = [K',N']
@@ -190,20 +195,20 @@ def _gemm_grads(items):
         slots.append((sx, sw))
     res = {'f': [None, None], 't': [None, None]}
     if fdx:
-        res['f'][0] = [K.gemm(fdx[i:i + _lib.MAX_GROUPS], trans=2) for i in range(0, len(fdx), _lib.MAX_GROUPS)]
+        res['f'][0] = [K.gemm(fdx[i:i + _lib.MAX_GROUPS], trans=2, res_acts=fra[i:i + _lib.MAX_GROUPS]) for i in range(0, len(fdx), _lib.MAX_GROUPS)]
         res['f'][0] = [t for g in res['f'][0] for t in g]
     if fdw:
         res['f'][1] = [K.gemm(fdw[i:i + _lib.MAX_GROUPS], trans=3, colsums=fdb[i:i + _lib.MAX_GROUPS]) for i in range(0, len(fdw), _lib.MAX_GROUPS)]
         res['f'][1] = [t for g in res['f'][1] for t in g]
     if tr:
         trs = K.transpose_pad_grouped(tr)
-        dxp = [(p[0], trs[p[1]], None, None) for p in dxp]
+        dxp = [(p[0], trs[p[1]], None, p[3]) for p in dxp]
         dwp = [(trs[p[0]], trs[p[1]], None, None) for p in dwp]
         if dxp and dwp and len(dxp) + len(dwp) <= _lib.MAX_GROUPS:
-            both = K.gemm(dxp + dwp)            # dgrad and wgrad problems of this backward in ONE grouped launch
+            both = K.gemm(dxp + dwp, res_acts=tra + [0] * len(dwp))            # dgrad and wgrad problems of this backward in ONE grouped launch
             res['t'][0], res['t'][1] = both[:len(dxp)], both[len(dxp):]
         else:
-            res['t'][0] = K.gemm(dxp) if dxp else []
+            res['t'][0] = K.gemm(dxp, res_acts=tra) if dxp else []
             res['t'][1] = K.gemm(dwp) if dwp else []
     outx = [None if sx is None else res[sx[0]][0][sx[1]] for sx, _ in slots]
     outw = [None if sw is None else res[sw[0]][1][sw[1]] for _, sw in slots]
@@ -378,6 +383,89 @@ class _LinearLNFn(torch.autograd.Function):
             dr = dz if (ctx.hasr[i] and ctx.needs_input_grad[6 + 6 * i]) else None
             res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw, db, dr, dg, dbt]
         return tuple(res)
+
+
+class _FFNFn(torch.autograd.Function):
+    """y_i = LN(drop(act(x_i W1_i^T + b1_i) W2_i^T + b2_i) + r_i) * gamma_i + beta_i, grouped: BertIntermediate + BertOutput
+    (vilmodel.py:190-217) as ONE autograd node.  Forward: the first GEMM's epilogue writes act(z) and z (c_pre); backward: the
+    second layer's dgrad leaves as (dY W2) * act'(z) (res_act): no activation kernel in either direction, and one node
+    instead of three."""
+
+    @staticmethod
+    def forward(ctx, n, eps, p_drop, act, *flat):
+        probs = [tuple(flat[8 * i:8 * i + 8]) for i in range(n)]      # x, w1, b1, w2, b2, r, gamma, beta
+        ctx.n, ctx.eps, ctx.act, ctx.p_drop = n, eps, act, p_drop
+        ctx.shapes = [p[0].shape for p in probs]
+        ctx.seed = dropout_seed() if p_drop > 0 else 0
+        with torch.no_grad():
+            hs, zs = K.gemm([(p[0], p[1], p[2], None) for p in probs], act, False, want_pre=True)
+            if p_drop > 0:
+                z2 = K.gemm([(h, p[3], p[4], None) for h, p in zip(hs, probs)], ACT_NONE, True)
+                ys = K.layernorm_grouped([(z, p[6], p[7], p[5]) for z, p in zip(z2, probs)], eps, probs[0][1].dtype, p_drop, ctx.seed)
+            else:
+                z2 = K.gemm([(h, p[3], p[4], p[5]) for h, p in zip(hs, probs)], ACT_NONE, True)
+                ys = K.layernorm_grouped([(z, p[6], p[7], None) for z, p in zip(z2, probs)], eps, probs[0][1].dtype)
+        ctx.hasr = [p[5] is not None for p in probs]
+        ctx.hasb = [(p[2] is not None, p[4] is not None) for p in probs]
+        saved = []
+        for p, z, h, zz in zip(probs, zs, hs, z2):
+            saved += [p[0], p[1], p[3], p[6], z, h, zz] + ([p[5]] if (p_drop > 0 and p[5] is not None) else [])
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        sv = list(ctx.saved_tensors)
+        it2, it1, keep = [], [], []
+        for i in range(ctx.n):
+            x, w1, w2, gamma, z, h, z2 = (sv.pop(0) for _ in range(7))
+            r = sv.pop(0) if (ctx.p_drop > 0 and ctx.hasr[i]) else None
+            dy = dys[i]
+            if dy is None:
+                keep.append(None)
+                continue
+            dy = dy if dy.dtype == w1.dtype else dy.to(w1.dtype)
+            ni = ctx.needs_input_grad
+            want_dr = ctx.hasr[i] and ni[9 + 8 * i]
+            if ctx.p_drop > 0:
+                dz, dlin, dg, dbt = K.layernorm_bwd(z2, r, gamma, dy, ctx.eps, ctx.p_drop, ctx.seed, i, want_dz=want_dr)
+            else:
+                dz, dg, dbt = K.layernorm_bwd(z2, None, gamma, dy, ctx.eps)
+                dlin = dz
+            keep.append((x, w1, z, dz if want_dr else None, dg, dbt))
+            # second layer: dW2 = dlin^T h, db2, and dZ = (dlin W2) * act'(z) straight out of the dgrad epilogue
+            it2.append((_as2d(h), w2, _as2d(dlin), True, ni[7 + 8 * i], ctx.hasb[i][1] and ni[8 + 8 * i], _as2d(z), ctx.act))
+        res = [None, None, None, None]
+        if not it2:
+            return tuple(res + [None] * (8 * ctx.n))
+        dzs, dw2s, db2s = _gemm_grads(it2)
+        live = [k for k in keep if k is not None]
+        for (x, w1, z, dr, dg, dbt), dz1, i in zip(live, dzs, [i for i, k in enumerate(keep) if k is not None]):
+            ni = ctx.needs_input_grad
+            it1.append((_as2d(x), w1, dz1, ni[4 + 8 * i], ni[5 + 8 * i], ctx.hasb[i][0] and ni[6 + 8 * i]))
+        dxs, dw1s, db1s = _gemm_grads(it1)
+        j = 0
+        for i in range(ctx.n):
+            if keep[i] is None:
+                res += [None] * 8
+                continue
+            x, w1, z, dr, dg, dbt = keep[i]
+            dx = dxs[j]
+            res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw1s[j], db1s[j], dw2s[j], db2s[j], dr, dg, dbt]
+            j += 1
+        return tuple(res)
+
+
+FUSED_FFN = __import__('os').environ.get('DSRG_FUSED_FFN', '1') == '1'       # 0: linear + activation + linear_ln nodes (A/B)
+
+
+def ffn_grouped(problems, eps, p_drop=0.0, act=ACT_GELU):
+    """problems: list of (x, w1, b1, w2, b2, residual|None, gamma, beta) -> list of LN(drop(act(x W1^T + b1) W2^T + b2) + residual)."""
+    flat = [t for p in problems for t in p]
+    if FUSED_FFN and _needs_grad(flat) and all(p[1].shape[0] % 8 == 0 for p in problems):
+        return list(_FFNFn.apply(len(problems), eps, float(p_drop), act, *flat))
+    inter = linear_grouped([(p[0], p[1], p[2], None) for p in problems], act=act)
+    return linear_ln_grouped([(h, p[3], p[4], p[5], p[6], p[7]) for h, p in zip(inter, problems)], eps, p_drop)
 
 
 def linear_ln_grouped(problems, eps, p_drop=0.0):

@@ -103,7 +103,7 @@ def _rows(t):
     return M, ld
 
 
-def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=None, trans=0, colsums=None):
+def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=None, trans=0, colsums=None, want_pre=False, res_acts=None):
     """problems: list of (x [..,K], w [N,K], bias fp32 [N] | None, residual [..,N] | None).
     Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32).  tile=(bm, bn, nst) pins the block tile
     (dsrg_gemm_nt_tiled; tuning only).
@@ -113,11 +113,13 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
     is un-normalised; 'stats_out': fp32 [M, N/64, 2] to receive this launch's partials; 'eps'.
     trans (dsrg_gemm_problem_t::trans, bf16 only): bit 0 - x is stored [K, M]; bit 1 - w is stored [K, N] (2-D tensors, row
     stride free): the backward GEMMs of a linear layer on dY, W and X as they lie.  colsums (trans bit 0): optional list of
-    fp32 [M] tensors (or None) that receive the column sums of the stored x (= the bias gradient with dW = dY^T.X)."""
+    fp32 [M] tensors (or None) that receive the column sums of the stored x (= the bias gradient with dW = dY^T.X).
+    want_pre: also return the pre-activations z = x w^T + b (input dtype) -> (outputs, pres) (dsrg_gemm_problem_t::c_pre).
+    res_acts: per problem, an activation id > 0 makes the epilogue MULTIPLY by act'(residual) instead of adding the residual."""
     lib = _lib.load()
     n = len(problems)
     arr = (_lib.GemmProblem * n)()
-    res = []
+    res, pres = [], []
     dt = _dt(problems[0][0])
     for i, (x, w, b, r) in enumerate(problems):
         _dev(x)
@@ -152,6 +154,12 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
             raise _lib.DsrgHipError('gemm: bad out rows / weight layout')
         arr[i] = _lib.GemmProblem(_p(x), _p(w), _p(b), _p(r), _p(out), M, N, K, lda, w.stride(0), ldr, ldc)
         arr[i].trans = trans
+        if want_pre:
+            pre = torch.empty(oshape, device=x.device, dtype=x.dtype)
+            arr[i].c_pre, arr[i].ldcp = _p(pre), _rows(pre)[1]
+            pres.append(pre)
+        if res_acts is not None and res_acts[i]:
+            arr[i].res_act = int(res_acts[i])
         if colsums is not None and colsums[i] is not None:
             cs = colsums[i]
             if not (trans & 1) or cs.dtype != torch.float32 or cs.numel() != M or not cs.is_contiguous():
@@ -184,6 +192,8 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
         _lib.check(lib.dsrg_gemm_nt_tiled(arr, n, dt, odt, act, tile[0], tile[1], tile[2] if len(tile) > 2 else 0, _stream()), 'dsrg_gemm_nt_tiled')
         return res
     _lib.check(lib.dsrg_gemm_nt(arr, n, dt, odt, act, _stream()), 'dsrg_gemm_nt')
+    if want_pre:
+        return res, pres
     if GEMM_TRACE is not None:
         bm, bn, nt, nst = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst))

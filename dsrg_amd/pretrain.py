@@ -135,8 +135,8 @@ class GlocalTextPathCMT(_Backbone):
             qkv = Fn.linear_grouped([(t[j], W[ks[j] + '.lqkv.w'], W[ks[j] + '.lqkv.b'], None) for j in range(2)])
             a = [Fn.attention_packed(qkv[j], nh, None, tm, MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
             t = self._grouped_res_ln(W, ks, '.lso', '.lsln', a, t, eps)
-            inter = Fn.linear_grouped([(t[j], W[ks[j] + '.lff1.w'], W[ks[j] + '.lff1.b'], None) for j in range(2)], act=ACT_GELU)
-            t = self._grouped_res_ln(W, ks, '.lff2', '.lfln', inter, t, eps)
+            t = Fn.ffn_grouped([(t[j], W[ks[j] + '.lff1.w'], W[ks[j] + '.lff1.b'], W[ks[j] + '.lff2.w'], W[ks[j] + '.lff2.b'], t[j],
+                                 W[ks[j] + '.lfln.g'], W[ks[j] + '.lfln.b']) for j in range(2)], eps, cfg.hidden_dropout_prob if self.training else 0.0)
         return t[0].float() + t[1].float()
 
     def forward(self, *a, **k):

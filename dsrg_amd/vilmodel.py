@@ -404,8 +404,9 @@ class GlocalTextPathNavCMT(nn.Module):
         qkv = Fn.linear(x, W[key + '.qkv.w'], W[key + '.qkv.b'])
         a = Fn.attention_packed(qkv, nh, None, kmask, mode, p_drop=self._attn_p())
         a = self._dense_res_ln(W, key + '.ao', key + '.aln', a, x, eps)
-        i = Fn.linear(a, W[key + '.ff1.w'], W[key + '.ff1.b'], act=ACT_GELU)
-        return self._dense_res_ln(W, key + '.ff2', key + '.fln', i, a, eps)
+        p = self.config.hidden_dropout_prob if self.training else 0.0
+        return Fn.ffn_grouped([(a, W[key + '.ff1.w'], W[key + '.ff1.b'], W[key + '.ff2.w'], W[key + '.ff2.b'], a, W[key + '.fln.g'], W[key + '.fln.b'])],
+                              eps, p)[0]
 
     # ---------------------------------------------------------------- language (vilmodel.py:678-688)
     def forward_text(self, txt_ids, txt_masks, act_txt=None, act_txt_masks=None, obj_txt=None, obj_txt_masks=None):
@@ -685,8 +686,8 @@ class GlocalTextPathNavCMT(nn.Module):
             a = Fn.attention_grouped_packed([(None, qkv[j], masks[j], dists if brs[j] == 'g' else None) for j in range(n)],
                                             nh, MASK_NEG10000, sw, sb, p_drop=self._attn_p())
             feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
-            inter = Fn.linear_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], None) for j in range(n)], act=ACT_GELU)
-            feats = self._grouped_res_ln(W, ks, '.ff2', '.fln', inter, feats, eps)
+            feats = Fn.ffn_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], W[ks[j] + '.ff2.w'], W[ks[j] + '.ff2.b'], feats[j],
+                                     W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b']) for j in range(n)], eps, self.config.hidden_dropout_prob if self.training else 0.0)
         return feats
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):

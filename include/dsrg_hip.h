@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 10
+#define DSRG_ABI_VERSION 11
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -73,6 +73,14 @@ typedef struct {
    * that belongs to dW = dY^T.X - written by plain stores (each m by exactly one workgroup: deterministic). */
   int32_t trans;
   float* a_colsum;
+  /* Activation in a training step, without activation kernels (BertIntermediate, FT/vilmodel.py:190-199 and its autograd):
+   *  - c_pre / ldcp (forward, with act != NONE): the pre-activation z = A W^T + bias is ALSO stored, in the input dtype, next
+   *    to C = act(z) (N, ldcp multiples of 8; no LayerNorm fusion);
+   *  - res_act (backward): DSRG_ACT_* > 0 makes the epilogue multiply by act'(residual[m,n]) instead of adding the residual:
+   *    with residual = that stored z, the dgrad GEMM of the NEXT layer leaves as dZ = (dY W2) * act'(z). */
+  void* c_pre;
+  int32_t ldcp;
+  int32_t res_act;
 } dsrg_gemm_problem_t;
 int dsrg_gemm_nt(const dsrg_gemm_problem_t* problems /*host*/, int nproblems, int dtype, int out_dtype,
                  int act, void* stream);

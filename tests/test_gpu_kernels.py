@@ -884,3 +884,56 @@ def test_linear_ln_fused_hidden_dropout(K, dtype, M, H):
     for a, b, name in zip(got, [t.grad for t in ref_leaves], ['x0', 'x1', 'w0', 'w1', 'b0', 'b1', 'r0', 'r1', 'g0', 'g1', 'bt0', 'bt1']):
         sc = max(1.0, b.abs().max().item())
         assert (a.float() - b).abs().max().item() <= (5e-4 if dtype == torch.float32 else 6e-2) * sc, name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K_,act', [(1920, 3072, 768, 1), (37, 128, 64, 2), (300, 776, 128, 3)])
+def test_gemm_pre_activation_output_and_act_grad_epilogue(K, dtype, M, N, K_, act):
+    """dsrg_gemm_problem_t::c_pre (forward: act(z) and z from one launch) and ::res_act (backward: (dY W) * act'(z) out of
+    the dgrad epilogue) against the separate activation kernels."""
+    x, w, b = _r(M, K_, dtype=dtype), _r(N, K_, seed=1, scale=0.05, dtype=dtype), _r(N, seed=2)
+    (y,), (z,) = K.gemm([(x, w, b, None)], act, False, want_pre=True)
+    z0 = K.gemm([(x, w, b, None)], 0, False)[0]
+    y0 = K.gemm([(x, w, b, None)], act, False)[0]
+    assert torch.equal(z, z0) and torch.equal(y, y0)
+    # backward: dz = (dy2 @ w2) * act'(z)
+    N2 = 256
+    dy2, w2 = _r(M, N2, seed=3, dtype=dtype), _r(N2, N, seed=4, scale=0.05, dtype=dtype)
+    ref = (dy2.float() @ w2.float()) * {1: lambda t: 0.5 * (1 + torch.erf(t / math.sqrt(2))) + t * torch.exp(-0.5 * t * t) / math.sqrt(2 * math.pi),
+                                         2: lambda t: (t > 0).float(), 3: lambda t: 1 - torch.tanh(t) ** 2}[act](z.float())
+    tol = (2e-4 if dtype == torch.float32 else 3e-2) * max(1.0, ref.abs().max().item())
+    if dtype == torch.bfloat16:
+        got = K.gemm([(dy2, w2, None, z)], trans=2, res_acts=[act])[0]
+        assert (got.float() - ref).abs().max().item() <= tol
+    got = K.gemm([(dy2, w2.T.contiguous(), None, z)], res_acts=[act])[0]
+    assert (got.float() - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_ffn_fused_node_matches_separate_nodes(K, dtype, p_drop):
+    """functional.ffn_grouped as one autograd node (pre-activation from the GEMM epilogue, activation backward inside the
+    dgrad epilogue) against linear + activation + linear_ln nodes: outputs and every gradient, same dropout seed."""
+    from dsrg_amd import functional as Fn
+    M, H, F_ = 650, 128, 512
+    torch.manual_seed(5)
+    mk = lambda *s, sc=1.0: torch.randn(*s, device='cuda') * sc
+    base = [mk(M, H).to(dtype), mk(F_, H, sc=0.05).to(dtype), mk(F_, sc=0.1), mk(H, F_, sc=0.05).to(dtype), mk(H, sc=0.1), 1 + mk(H, sc=0.1), mk(H, sc=0.1)]
+    go = mk(M, H).to(dtype)
+    outs = []
+    for fused in (True, False):
+        lv = [t.clone().requires_grad_(True) for t in base]
+        x, w1, b1, w2, b2, g, bt = lv
+        Fn.FUSED_FFN = fused
+        orig = Fn.dropout_seed
+        Fn.dropout_seed = lambda: 4242
+        try:
+            y = Fn.ffn_grouped([(x, w1, b1, w2, b2, x, g, bt)], 1e-12, p_drop)[0]
+        finally:
+            Fn.dropout_seed = orig
+            Fn.FUSED_FFN = True
+        y.backward(go)
+        outs.append([y.detach()] + [t.grad for t in lv])
+    tol = 1e-4 if dtype == torch.float32 else 5e-2      # bf16: the separate path applies GELU to the bf16-rounded pre-activation
+    for a, b, name in zip(outs[0], outs[1], ['y', 'x', 'w1', 'b1', 'w2', 'b2', 'gamma', 'beta']):
+        assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item()), name

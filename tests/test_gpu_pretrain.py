@@ -44,6 +44,12 @@ def test_pretrain_losses_and_grads(dtype):
             if k.startswith(task + '_grad:'):
                 mine = named[k.split(':', 1)[1]].grad.reshape(-1)[:64].float().cpu().numpy()
                 tol = (2e-3 if fp32 else 2.5e-1) * np.abs(gg).max() + 1e-6
+                if not fp32:
+                    # bf16: the error of a parameter's gradient scales with the backward signal that passes through it, not with
+                    # its own magnitude - the GAA weight (max |g| 5e-3 of a gradient of norm 41, sums that cancel) sits at
+                    # 0.0005 .. 0.3 relative error depending on nothing but the rounding pattern, while the error over ALL
+                    # parameters stays at 7.5 % relative L2 (tools/dbg/pt_rev_ffn.py).  Hence a floor of 1e-4 of the gradient norm.
+                    tol += 1e-4 * float(gold[task + '_gradnorm'][0])
                 assert np.abs(mine - gg).max() <= tol, (k, np.abs(mine - gg).max(), np.abs(gg).max())
         with torch.no_grad():
             o = m(b, task, compute_loss=False)
@@ -97,6 +103,12 @@ def test_pretrain_reverie_losses_and_grads(dtype):
             if k.startswith(task + '_grad:'):
                 mine = named[k.split(':', 1)[1]].grad.reshape(-1)[:64].float().cpu().numpy()
                 tol = (2e-3 if fp32 else 2.5e-1) * np.abs(gg).max() + 1e-6
+                if not fp32:
+                    # bf16: the error of a parameter's gradient scales with the backward signal that passes through it, not with
+                    # its own magnitude - the GAA weight (max |g| 5e-3 of a gradient of norm 41, sums that cancel) sits at
+                    # 0.0005 .. 0.3 relative error depending on nothing but the rounding pattern, while the error over ALL
+                    # parameters stays at 7.5 % relative L2 (tools/dbg/pt_rev_ffn.py).  Hence a floor of 1e-4 of the gradient norm.
+                    tol += 1e-4 * float(gold[task + '_gradnorm'][0])
                 bad = int((np.abs(mine - gg) > tol).sum())
                 # bf16: a ReLU input within bf16 rounding of zero can take the other branch (og_head column 24: z = -0.0035
                 # in fp32, +0.0008 in bf16, on one of 18 object rows), which moves that one column's gradient by the row's
