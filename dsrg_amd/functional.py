@@ -406,6 +406,7 @@ class _FFNFn(torch.autograd.Function):
                 z2 = K.gemm([(h, p[3], p[4], p[5]) for h, p in zip(hs, probs)], ACT_NONE, True)
                 ys = K.layernorm_grouped([(z, p[6], p[7], None) for z, p in zip(z2, probs)], eps, probs[0][1].dtype)
         ctx.hasr = [p[5] is not None for p in probs]
+        ctx.same = [p[5] is p[0] for p in probs]       # the residual IS the block input (BertOutput): one gradient, summed in the dgrad epilogue
         ctx.hasb = [(p[2] is not None, p[4] is not None) for p in probs]
         saved = []
         for p, z, h, zz in zip(probs, zs, hs, z2):
@@ -439,10 +440,16 @@ class _FFNFn(torch.autograd.Function):
         if not it2:
             return tuple(res + [None] * (8 * ctx.n))
         dzs, dw2s, db2s = _gemm_grads(it2)
+        merged = set()
         live = [k for k in keep if k is not None]
         for (x, w1, z, dr, dg, dbt), dz1, i in zip(live, dzs, [i for i, k in enumerate(keep) if k is not None]):
             ni = ctx.needs_input_grad
-            it1.append((_as2d(x), w1, dz1, ni[4 + 8 * i], ni[5 + 8 * i], ctx.hasb[i][0] and ni[6 + 8 * i]))
+            if ctx.same[i] and dr is not None and ni[4 + 8 * i] and dr.dtype == dz1.dtype:
+                # dX = dZ1 W1 + dR out of one epilogue (torch.autograd would add the two with a kernel of its own)
+                it1.append((_as2d(x), w1, dz1, True, ni[5 + 8 * i], ctx.hasb[i][0] and ni[6 + 8 * i], _as2d(dr), 0))
+                merged.add(i)
+            else:
+                it1.append((_as2d(x), w1, dz1, ni[4 + 8 * i], ni[5 + 8 * i], ctx.hasb[i][0] and ni[6 + 8 * i]))
         dxs, dw1s, db1s = _gemm_grads(it1)
         j = 0
         for i in range(ctx.n):
@@ -451,9 +458,133 @@ class _FFNFn(torch.autograd.Function):
                 continue
             x, w1, z, dr, dg, dbt = keep[i]
             dx = dxs[j]
-            res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw1s[j], db1s[j], dw2s[j], db2s[j], dr, dg, dbt]
+            res += [dx.view(ctx.shapes[i]) if dx is not None else None, dw1s[j], db1s[j], dw2s[j], db2s[j], None if i in merged else dr, dg, dbt]
             j += 1
         return tuple(res)
+
+
+class _AttnBlockFn(torch.autograd.Function):
+    """y_i = LN(drop(attention(..) Wo_i^T + bo_i) + x_i), grouped: BertAttention / BertXAttention + BertSelfOutput
+    (vilmodel.py:111-177, 349-392) as ONE autograd node instead of three (projection, attention, dense+LN).
+      self  (kv_i is None): q | k | v = x_i Wq_i^T + bq_i with Wq_i the packed [3H, H] projection;
+      cross (kv_i given)  : q = x_i Wq_i^T + bq_i, k | v = kv_i (a packed [B, Nk, 2H] projection of the other modality).
+    Backward: LayerNorm backward (hidden dropout recomputed), the output projection's dgrad / wgrad, the attention backward
+    writing into packed gradients, and the input projection's dgrad with the residual's gradient added in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, n, cfg, *flat):
+        nh, mask_mode, scale, p_attn, p_hid, eps = cfg
+        H = nh * 64
+        probs = [tuple(flat[10 * i:10 * i + 10]) for i in range(n)]    # x, wq, bq, wo, bo, gamma, beta, kv, kmask, dists
+        sw, sb = flat[10 * n], flat[10 * n + 1]
+        ctx.n, ctx.cfg = n, cfg
+        ctx.hid_seed = dropout_seed() if p_hid > 0 else 0
+        ctx.att_seeds = [dropout_seed() if p_attn > 0 else 0 for _ in range(n)]
+        with torch.no_grad():
+            qs = K.gemm([(p[0], p[1], p[2], None) for p in probs])
+            outs, lses = [], []
+            for q, p, sd in zip(qs, probs, ctx.att_seeds):
+                kv, km, d = p[7], p[8], p[9]
+                qq, k, v = (q[..., :H], q[..., H:2 * H], q[..., 2 * H:]) if kv is None else (q, kv[..., :H], kv[..., H:])
+                o, l = K.attention(qq, k, v, nh, km, mask_mode if km is not None else MASK_NONE, d, sw if d is not None else None,
+                                   sb if d is not None else None, scale, want_lse=True, p_drop=p_attn, seed=sd)
+                outs.append(o); lses.append(l)
+            if p_hid > 0:
+                z2 = K.gemm([(o, p[3], p[4], None) for o, p in zip(outs, probs)], ACT_NONE, True)
+                ys = K.layernorm_grouped([(z, p[5], p[6], p[0]) for z, p in zip(z2, probs)], eps, probs[0][1].dtype, p_hid, ctx.hid_seed)
+            else:
+                z2 = K.gemm([(o, p[3], p[4], p[0]) for o, p in zip(outs, probs)], ACT_NONE, True)
+                ys = K.layernorm_grouped([(z, p[5], p[6], None) for z, p in zip(z2, probs)], eps, probs[0][1].dtype)
+        ctx.hasb = [(p[2] is not None, p[4] is not None) for p in probs]
+        ctx.cross = [p[7] is not None for p in probs]
+        ctx.hasd = [p[9] is not None for p in probs]
+        saved = [sw, sb]
+        for p, q, o, l, z in zip(probs, qs, outs, lses, z2):
+            saved += [p[0], p[1], p[3], p[5], p[7], p[8], p[9], q, o, l, z]
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        nh, mask_mode, scale, p_attn, p_hid, eps = ctx.cfg
+        H = nh * 64
+        sv = list(ctx.saved_tensors)
+        sw, sb = sv.pop(0), sv.pop(0)
+        ni = ctx.needs_input_grad
+        st, it_o = [], []
+        for i in range(ctx.n):
+            x, wq, wo, gamma, kv, km, d, q, o, l, z2 = (sv.pop(0) for _ in range(11))
+            dy = dys[i]
+            if dy is None:
+                st.append(None)
+                continue
+            dy = dy if dy.dtype == wq.dtype else dy.to(wq.dtype)
+            if p_hid > 0:
+                dz, dlin, dg, dbt = K.layernorm_bwd(z2, x, gamma, dy, eps, p_hid, ctx.hid_seed, i, want_dz=ni[2 + 10 * i])
+            else:
+                dz, dg, dbt = K.layernorm_bwd(z2, None, gamma, dy, eps)
+                dlin = dz
+            st.append([x, wq, kv, km, d, q, o, l, dz if ni[2 + 10 * i] else None, dg, dbt])
+            it_o.append((_as2d(o), wo, _as2d(dlin), True, ni[5 + 10 * i], ctx.hasb[i][1] and ni[6 + 10 * i]))
+        res = [None, None]
+        if not it_o:
+            return tuple(res + [None] * (10 * ctx.n + 2))
+        douts, dwos, dbos = _gemm_grads(it_o)
+        it_q, dkvs, dsp_sum = [], [], None
+        j = 0
+        for i in range(ctx.n):
+            if st[i] is None:
+                dkvs.append(None)
+                continue
+            x, wq, kv, km, d, q, o, l, dz, dg, dbt = st[i]
+            do = douts[j].view(o.shape)
+            dqp = torch.empty(q.shape, device=q.device, dtype=q.dtype)
+            if kv is None:
+                qq, k, v = q[..., :H], q[..., H:2 * H], q[..., 2 * H:]
+                grads, dkv = (dqp[..., :H], dqp[..., H:2 * H], dqp[..., 2 * H:]), None
+            else:
+                qq, k, v = q, kv[..., :H], kv[..., H:]
+                dkv = torch.empty(kv.shape, device=kv.device, dtype=kv.dtype)
+                grads = (dqp, dkv[..., :H], dkv[..., H:])
+            _, _, _, dsp = K.attention_bwd(qq, k, v, o, do, l, nh, km, mask_mode if km is not None else MASK_NONE, d, sw if d is not None else None,
+                                           sb if d is not None else None, scale, p_attn, ctx.att_seeds[i], grads=grads)
+            if dsp is not None:
+                dsp_sum = dsp if dsp_sum is None else dsp_sum + dsp
+            dkvs.append(dkv)
+            if dz is not None and ni[2 + 10 * i] and dz.dtype == dqp.dtype:
+                it_q.append((_as2d(x), wq, _as2d(dqp), True, ni[3 + 10 * i], ctx.hasb[i][0] and ni[4 + 10 * i], _as2d(dz), 0))    # dX = dQ Wq + dR
+            else:
+                it_q.append((_as2d(x), wq, _as2d(dqp), ni[2 + 10 * i], ni[3 + 10 * i], ctx.hasb[i][0] and ni[4 + 10 * i]))
+            j += 1
+        dxs, dwqs, dbqs = _gemm_grads(it_q)
+        j = 0
+        for i in range(ctx.n):
+            if st[i] is None:
+                res += [None] * 10
+                continue
+            x, dg, dbt = st[i][0], st[i][9], st[i][10]
+            dx = dxs[j]
+            res += [dx.view(x.shape) if dx is not None else None, dwqs[j], dbqs[j], dwos[j], dbos[j], dg, dbt, dkvs[i], None, None]
+            j += 1
+        dsw = dsb = None
+        if dsp_sum is not None and sw is not None:
+            dsw, dsb = dsp_sum[0:1].reshape(sw.shape).to(sw.dtype), dsp_sum[1:2].reshape(sb.shape).to(sb.dtype)
+        return tuple(res + [dsw, dsb])
+
+
+FUSED_ATTN_BLOCK = __import__('os').environ.get('DSRG_FUSED_ATTN_BLOCK', '1') == '1'     # 0: projection / attention / dense+LN nodes (A/B)
+
+
+def attn_block_grouped(problems, nh, mask_mode, eps, p_attn=0.0, p_hid=0.0, sprel_w=None, sprel_b=None, scale=0.125):
+    """problems: list of (x, wq, bq, wo, bo, gamma, beta, kv | None, kmask | None, dists | None) ->
+    list of LN(drop(attention Wo^T + bo) + x); see _AttnBlockFn.  Without autograd: the grouped launches of the parts."""
+    flat = [t for p in problems for t in p] + [sprel_w, sprel_b]
+    if FUSED_ATTN_BLOCK and _needs_grad(flat) and all(p[0].dim() == 3 and (p[7] is None or p[7].stride(-1) == 1) for p in problems):
+        return list(_AttnBlockFn.apply(len(problems), (nh, mask_mode, scale, float(p_attn), float(p_hid), eps), *flat))
+    q = linear_grouped([(p[0], p[1], p[2], None) for p in problems])
+    a = attention_grouped_packed([(None if p[7] is None else q[j], q[j] if p[7] is None else p[7], p[8], p[9]) for j, p in enumerate(problems)],
+                                 nh, mask_mode, sprel_w, sprel_b, scale, p_attn)
+    return linear_ln_grouped([(a[j], p[3], p[4], p[0], p[5], p[6]) for j, p in enumerate(problems)], eps, p_hid)
 
 
 FUSED_FFN = __import__('os').environ.get('DSRG_FUSED_FFN', '1') == '1'       # 0: linear + activation + linear_ln nodes (A/B)

@@ -128,13 +128,12 @@ class GlocalTextPathCMT(_Backbone):
         t = [txt, txt]
         for i in range(nl):
             ks = ['x.%s.%d' % (br, i) for br in brs]
-            q = Fn.linear_grouped([(t[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(2)])
+            ph = cfg.hidden_dropout_prob if self.training else 0.0
             kv = Fn.linear_grouped([(ctx[j], W[ks[j] + '.ckv.w'], W[ks[j] + '.ckv.b'], None) for j in range(2)])
-            a = [Fn.attention_packed(kv[j], nh, q[j], cmask[j], MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
-            t = self._grouped_res_ln(W, ks, '.co', '.cln', a, t, eps)
-            qkv = Fn.linear_grouped([(t[j], W[ks[j] + '.lqkv.w'], W[ks[j] + '.lqkv.b'], None) for j in range(2)])
-            a = [Fn.attention_packed(qkv[j], nh, None, tm, MASK_NEG10000, p_drop=self._attn_p()) for j in range(2)]
-            t = self._grouped_res_ln(W, ks, '.lso', '.lsln', a, t, eps)
+            t = Fn.attn_block_grouped([(t[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], W[ks[j] + '.co.w'], W[ks[j] + '.co.b'], W[ks[j] + '.cln.g'],
+                                        W[ks[j] + '.cln.b'], kv[j], cmask[j], None) for j in range(2)], nh, MASK_NEG10000, eps, self._attn_p(), ph)
+            t = Fn.attn_block_grouped([(t[j], W[ks[j] + '.lqkv.w'], W[ks[j] + '.lqkv.b'], W[ks[j] + '.lso.w'], W[ks[j] + '.lso.b'], W[ks[j] + '.lsln.g'],
+                                        W[ks[j] + '.lsln.b'], None, tm, None) for j in range(2)], nh, MASK_NEG10000, eps, self._attn_p(), ph)
             t = Fn.ffn_grouped([(t[j], W[ks[j] + '.lff1.w'], W[ks[j] + '.lff1.b'], W[ks[j] + '.lff2.w'], W[ks[j] + '.lff2.b'], t[j],
                                  W[ks[j] + '.lfln.g'], W[ks[j] + '.lfln.b']) for j in range(2)], eps, cfg.hidden_dropout_prob if self.training else 0.0)
         return t[0].float() + t[1].float()

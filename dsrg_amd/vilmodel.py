@@ -401,10 +401,9 @@ class GlocalTextPathNavCMT(nn.Module):
 
     def _bert_layer(self, W, key, x, nh, kmask, mode):  # vilmodel.py:226-232
         H, eps = x.shape[-1], self.config.layer_norm_eps
-        qkv = Fn.linear(x, W[key + '.qkv.w'], W[key + '.qkv.b'])
-        a = Fn.attention_packed(qkv, nh, None, kmask, mode, p_drop=self._attn_p())
-        a = self._dense_res_ln(W, key + '.ao', key + '.aln', a, x, eps)
         p = self.config.hidden_dropout_prob if self.training else 0.0
+        a = Fn.attn_block_grouped([(x, W[key + '.qkv.w'], W[key + '.qkv.b'], W[key + '.ao.w'], W[key + '.ao.b'], W[key + '.aln.g'], W[key + '.aln.b'],
+                                    None, kmask, None)], nh, mode, eps, self._attn_p(), p)[0]
         return Fn.ffn_grouped([(a, W[key + '.ff1.w'], W[key + '.ff1.b'], W[key + '.ff2.w'], W[key + '.ff2.b'], a, W[key + '.fln.g'], W[key + '.fln.b'])],
                               eps, p)[0]
 
@@ -678,14 +677,13 @@ class GlocalTextPathNavCMT(nn.Module):
         kvs = Fn.split_cols(kv, [2 * H] * (kv.shape[-1] // (2 * H)))      # the text K|V panel of every (branch, layer)
         for i in range(nl):
             ks = ['x.%s.%d' % (b, i) for b in brs]
-            q = Fn.linear_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], None) for j in range(n)])
-            a = Fn.attention_grouped_packed([(q[j], kvs[('g', 'l').index(brs[j]) * nl + i], txt_masks, None) for j in range(n)],
-                                            nh, MASK_NEG10000, p_drop=self._attn_p())
-            feats = self._grouped_res_ln(W, ks, '.co', '.cln', a, feats, eps)
-            qkv = Fn.linear_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], None) for j in range(n)])
-            a = Fn.attention_grouped_packed([(None, qkv[j], masks[j], dists if brs[j] == 'g' else None) for j in range(n)],
-                                            nh, MASK_NEG10000, sw, sb, p_drop=self._attn_p())
-            feats = self._grouped_res_ln(W, ks, '.so', '.sln', a, feats, eps)
+            ph = self.config.hidden_dropout_prob if self.training else 0.0
+            feats = Fn.attn_block_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], W[ks[j] + '.co.w'], W[ks[j] + '.co.b'], W[ks[j] + '.cln.g'],
+                                            W[ks[j] + '.cln.b'], kvs[('g', 'l').index(brs[j]) * nl + i], txt_masks, None) for j in range(n)],
+                                          nh, MASK_NEG10000, eps, self._attn_p(), ph)
+            feats = Fn.attn_block_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], W[ks[j] + '.so.w'], W[ks[j] + '.so.b'], W[ks[j] + '.sln.g'],
+                                            W[ks[j] + '.sln.b'], None, masks[j], dists if brs[j] == 'g' else None) for j in range(n)],
+                                          nh, MASK_NEG10000, eps, self._attn_p(), ph, sw, sb)
             feats = Fn.ffn_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], W[ks[j] + '.ff2.w'], W[ks[j] + '.ff2.b'], feats[j],
                                      W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b']) for j in range(n)], eps, self.config.hidden_dropout_prob if self.training else 0.0)
         return feats

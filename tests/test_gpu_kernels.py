@@ -937,3 +937,45 @@ def test_ffn_fused_node_matches_separate_nodes(K, dtype, p_drop):
     tol = 1e-4 if dtype == torch.float32 else 5e-2      # bf16: the separate path applies GELU to the bf16-rounded pre-activation
     for a, b, name in zip(outs[0], outs[1], ['y', 'x', 'w1', 'b1', 'w2', 'b2', 'gamma', 'beta']):
         assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item()), name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('cross,p_hid', [(False, 0.0), (False, 0.1), (True, 0.0), (True, 0.1)])
+def test_attention_block_fused_node_matches_separate_nodes(K, dtype, cross, p_hid):
+    """functional.attn_block_grouped as one autograd node against projection + attention + dense/LayerNorm nodes: two
+    grouped problems (one with the sprel bias), outputs and every gradient incl. d(kv) and d(sprel)."""
+    from dsrg_amd import functional as Fn
+    B, nh = 3, 2
+    H = nh * 64
+    Nq, Nk = (20, 38), (33, 38)
+    torch.manual_seed(11)
+    mk = lambda *s, sc=1.0: torch.randn(*s, device='cuda') * sc
+    base, masks, dists = [], [], []
+    for j in range(2):
+        nk = Nk[j] if cross else Nq[j]
+        base.append([mk(B, Nq[j], H).to(dtype), mk(H if cross else 3 * H, H, sc=0.08).to(dtype), mk(H if cross else 3 * H, sc=0.1), mk(H, H, sc=0.08).to(dtype),
+                     mk(H, sc=0.1), 1 + mk(H, sc=0.1), mk(H, sc=0.1), mk(B, nk, 2 * H).to(dtype) if cross else None])
+        masks.append(torch.arange(nk, device='cuda')[None] < torch.tensor([nk, 5, nk - 2], device='cuda')[:, None])
+        dists.append(torch.rand(B, Nq[j], nk, device='cuda') if (j == 0 and not cross) else None)
+    sw0, sb0 = torch.tensor([[0.3]], device='cuda'), torch.tensor([0.1], device='cuda')
+    gos = [mk(B, Nq[j], H).to(dtype) for j in range(2)]
+    outs = []
+    for fused in (True, False):
+        lv = [[None if t is None else t.clone().requires_grad_(True) for t in b] for b in base]
+        sw, sb = sw0.clone().requires_grad_(True), sb0.clone().requires_grad_(True)
+        Fn.FUSED_ATTN_BLOCK = fused
+        orig = Fn.dropout_seed
+        Fn.dropout_seed = lambda: 777
+        try:
+            ys = Fn.attn_block_grouped([tuple(lv[j][:7]) + (lv[j][7], masks[j], dists[j]) for j in range(2)], nh, 1, 1e-12, 0.0, p_hid,
+                                       None if cross else sw, None if cross else sb)
+        finally:
+            Fn.dropout_seed = orig
+            Fn.FUSED_ATTN_BLOCK = True
+        torch.autograd.backward(ys, gos)
+        outs.append([y.detach() for y in ys] + [t.grad for b in lv for t in b if t is not None] + ([] if cross else [sw.grad, sb.grad]))
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert len(outs[0]) == len(outs[1])
+    for idx, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert a is not None and b is not None, idx
+        assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item()), idx

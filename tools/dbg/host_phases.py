@@ -37,11 +37,11 @@ def step(i, rec):
             acc[k] += v
 for i in range(6): step(i, False)
 acc.clear()
-torch.cuda.synchronize(); t = pc()
+torch.cuda.synchronize(); t = pc(); c0 = time.process_time()
 N = 30
 for i in range(N): step(i, True)
-th = pc() - t
+th = pc() - t; cpu = time.process_time() - c0
 torch.cuda.synchronize()
-print('host %.2f ms/step, wall %.2f ms/step' % (th / N * 1e3, (pc() - t) / N * 1e3))
+print('host %.2f ms/step, wall %.2f ms/step, process CPU time %.2f ms/step' % (th / N * 1e3, (pc() - t) / N * 1e3, cpu / N * 1e3))
 for k, v in acc.items():
     print('%-32s %.2f ms/step' % (k, v / N * 1e3))
