@@ -34,6 +34,16 @@ def _foreach_copy_grouped(dsts, srcs):
 # dsrg_amd.distributed.wrap_model switches this on.
 MATERIALIZE_UNUSED_GRADS = False
 
+# Packed / cast copies of the parameters are cached per parameter version.  Tensor._version does NOT move under fused
+# optimizers (torch.optim.AdamW(fused=True)) nor under optimizers that write through `.data` (the reference's own AdamW,
+# pretrain_src/optim/adamw.py), so every cache key also carries this counter, which every backward pass through a pack
+# advances: an optimizer step is always preceded by one.
+PACK_EPOCH = [0]
+
+
+def pack_version(srcs):
+    return (PACK_EPOCH[0],) + tuple(p._version for p in srcs)
+
 
 class _PackFn(torch.autograd.Function):
     """All compute-dtype / packed copies of the parameters in one autograd node: forward = one multi-tensor copy
@@ -61,6 +71,7 @@ class _PackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        PACK_EPOCH[0] += 1           # the parameters are about to change: no cached pack survives this backward
         grads = [None] * len(ctx.meta)
         dst, src = [], []
         for (dtype, idxs), g in zip(ctx.spec, gouts):

@@ -219,7 +219,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def _hw_resolve(self, plan):
         """one pack per parameter version and grad mode (see GlocalTextPathNavCMT._resolve_weights)"""
         W0, pk, _ = plan
-        key = (torch.is_grad_enabled(), tuple(p._version for p in pk.srcs))
+        key = (torch.is_grad_enabled(), Fn.pack_version(pk.srcs))
         if self._hwres is not None and self._hwres[0] == key:
             return self._hwres[1]
         W = pk.resolve(dict(W0))

@@ -22,6 +22,7 @@ re-captures when the model re-packs them (eval() / train() / .to() / load_state_
 import torch
 
 from ._lib import DsrgHipError
+from . import functional as Fn
 
 
 class GraphedNavStep:
@@ -89,7 +90,7 @@ class GraphedNavStep:
 
     def _pack_version(self):
         plan = self.model._wplan
-        return None if plan is None else tuple(p._version for p in plan[1].srcs)
+        return None if plan is None else Fn.pack_version(plan[1].srcs)
 
     def _check_weights(self):
         """The model dropped or re-packed its weight cache since capture -> capture again (cheap next to serving stale

@@ -262,7 +262,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if not grad and self._wcache is not None:
             # eval(): weights are frozen until the next train()/eval()/load_state_dict() (those invalidate); a no-grad
             # forward of a model in train() mode may follow an optimizer.step(), so there the versions are compared
-            if not self.training or self._wcache_ver == tuple(p._version for p in plan[1].srcs):
+            if not self.training or self._wcache_ver == Fn.pack_version(plan[1].srcs):
                 return self._wcache
         if plan is not None:
             return self._resolve_weights(plan, grad)
@@ -356,7 +356,7 @@ class GlocalTextPathNavCMT(nn.Module):
         pack and one _PackFn node.  (Writing through `.data` bypasses the version counter: call invalidate_caches().)"""
         W0, pk, _ = plan
         if grad:
-            ver = tuple(p._version for p in pk.srcs)
+            ver = Fn.pack_version(pk.srcs)
             if self._wgrad is not None and self._wgrad[0] == ver:
                 return self._wgrad[1]
         W = pk.resolve(dict(W0))
@@ -364,7 +364,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if grad:
             self._wgrad = (ver, W)
         else:
-            self._wcache, self._wcache_ver = W, tuple(p._version for p in pk.srcs)
+            self._wcache, self._wcache_ver = W, Fn.pack_version(pk.srcs)
         return W
 
     def _cls_head_weights(self, W, key, hd, lin, ln, f):

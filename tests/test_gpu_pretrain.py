@@ -157,3 +157,56 @@ def test_ddp_wrapper_with_task_dependent_parameters():
         Fn.MATERIALIZE_UNUSED_GRADS = False
         if own:
             dist.destroy_process_group()
+
+
+class _DataSGD(torch.optim.Optimizer):
+    """an optimizer that writes through `.data` like the reference's own AdamW (pretrain_src/optim/adamw.py): no version bump"""
+
+    def __init__(self, params, lr):
+        super().__init__(params, {'lr': lr})
+
+    @torch.no_grad()
+    def step(self):
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is not None:
+                    p.data.add_(p.grad.data, alpha=-g['lr'])
+
+
+@pytest.mark.parametrize('make_opt', [lambda ps: torch.optim.AdamW(ps, lr=1e-3, fused=True), lambda ps: torch.optim.AdamW(ps, lr=1e-3),
+                                       lambda ps: _DataSGD(ps, 1e-2)], ids=['adamw-fused', 'adamw-foreach', 'data-sgd'])
+def test_forward_sees_the_optimizer_step(make_opt):
+    """The packed / cast weight copies must follow EVERY kind of optimizer step - fused optimizers and optimizers that write
+    through `.data` do not move Tensor._version - in grad mode and in a no-grad forward of the train()-mode model: after two
+    steps the model must agree with a freshly built model that loads its state_dict."""
+    gold = common.load_gold('r2r_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    m = _model(torch.float32)
+    m.eval(); m.train()      # train mode, but no dropout in PT_CFG? keep it deterministic below by comparing no-grad eval forwards
+    opt = make_opt([p for p in m.parameters() if p.requires_grad])
+    b = common.to_t(synth.pretrain_batch(B, L, O, seed, 'sap'), 'cuda')
+    with torch.no_grad():
+        first = m(b, 'sap', compute_loss=False)[0].clone()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        m(b, 'sap', compute_loss=True).mean().backward()
+        opt.step()
+        with torch.no_grad():
+            mid = m(b, 'sap', compute_loss=False)[0].clone()       # a no-grad forward of the train()-mode model right after a step
+    m2 = _model(torch.float32)
+    m2.load_state_dict(m.state_dict())
+    for mm in (m, m2):
+        mm.eval()
+    with torch.no_grad():
+        a, c = m(b, 'sap', compute_loss=False)[0], m2(b, 'sap', compute_loss=False)[0]
+    fin = torch.isfinite(c)
+    assert (a[fin] - c[fin]).abs().max().item() <= 1e-4
+    assert (a[fin] - first[fin]).abs().max().item() > 1e-3          # the steps did move the logits
+    assert (mid[fin] - a[fin]).abs().max().item() <= 1e-4           # ... and the no-grad forward right after the step saw them (no dropout in PT_CFG)
+    m.train()
+    opt.zero_grad(set_to_none=True)
+    l1 = m(b, 'sap', compute_loss=True)
+    m2.train()
+    l2 = m2(b, 'sap', compute_loss=True)
+    if float(PT_CFG.get('hidden_dropout_prob', 0.0)) == 0.0:
+        assert (l1 - l2).abs().max().item() <= 1e-4                # grad-mode pack refreshed as well

@@ -16,6 +16,10 @@ opt = torch.optim.AdamW(params, lr=5e-5, betas=(0.9, 0.98), fused=True)
 batches = {t: bench.T(synth.pretrain_batch(bench.PT_B, bench.PT_L, 3, 200, t, min_steps=4, max_steps=7), dev) for t in bench.PT_TASKS}
 acc = collections.defaultdict(float)
 pc = time.perf_counter
+orig_resolve = Fn.WeightPacker.resolve
+def timed_resolve(self, W):
+    t = pc(); r = orig_resolve(self, W); acc['  pack resolve (inside forward)'] += pc() - t; return r
+Fn.WeightPacker.resolve = timed_resolve
 orig_apply = Fn._PackFn.apply
 def timed_pack(*a):
     t = pc(); r = orig_apply(*a); acc['  pack fwd (inside forward)'] += pc() - t; return r
