@@ -53,6 +53,24 @@ class _PackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, *srcs):
+        plan = getattr(spec, 'plan', None)
+        if plan is not None or (isinstance(spec, _Spec) and all(s.is_contiguous() for s in srcs)):
+            # Everything that does not change from step to step (detached flat aliases of the parameters, the layout of the
+            # packed buffers, the grouping by dtype pair) is computed once per packer: a step then costs one allocation and one
+            # split per output dtype, the multi-tensor copies, and one view per output - not ~4 tensor ops per parameter.
+            if plan is None:
+                plan = spec.plan = _pack_plan(spec, srcs)
+            flats = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
+            parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
+            for (dd, sd), (pidx, dets) in plan['copies'].items():
+                pp = parts[dd]
+                torch._foreach_copy_([pp[j] for j in pidx], dets)
+            outs = [torch.as_strided(flats[d], shape, strides, off) for d, shape, strides, off in plan['outs']]
+            if isinstance(ctx, torch.autograd.function.FunctionCtx):
+                ctx.set_materialize_grads(False)
+            ctx.spec = spec
+            ctx.meta = plan['meta']
+            return tuple(outs)
         outs, dst = [], []
         for dtype, idxs in spec:
             rows = sum(srcs[i].shape[0] for i in idxs)
@@ -101,6 +119,35 @@ class _PackFn(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class _Spec(tuple):
+    """the packer's (dtype, source indices) groups; a tuple subclass so that the static part of the pack (`plan`) can ride on it"""
+    plan = None
+
+
+def _pack_plan(spec, srcs):
+    dev = srcs[0].device
+    total, sizes, copies, outs = {}, {}, {}, []
+    for dtype, idxs in spec:
+        off = total.get(dtype, 0)
+        sz = sizes.setdefault(dtype, [])
+        pad = (-off) % 64                      # every packed tensor starts on a 64-element boundary (16-byte aligned rows for the GEMM)
+        if pad:
+            sz.append(pad); off += pad
+        rows = sum(srcs[i].shape[0] for i in idxs)
+        shape = (rows,) + tuple(srcs[idxs[0]].shape[1:])
+        st, acc = [], 1
+        for d_ in reversed(shape):
+            st.append(acc); acc *= d_
+        outs.append((dtype, shape, tuple(reversed(st)), off))
+        for i in idxs:
+            n = srcs[i].numel()
+            g = copies.setdefault((dtype, srcs[i].dtype), ([], []))
+            g[0].append(len(sz)); g[1].append(srcs[i].detach().view(-1))
+            sz.append(n); off += n
+        total[dtype] = off
+    return {'dev': dev, 'total': total, 'sizes': sizes, 'copies': copies, 'outs': outs, 'meta': [(t.shape, t.dtype, t.device) for t in srcs]}
+
+
 class WeightPacker:
     """Collects cast / concat requests while a weight dict is being built and serves them with one _PackFn call.
     `cast(t)` / `cat(ts)` return placeholders; `resolve(W)` swaps them for the packed tensors."""
@@ -129,11 +176,14 @@ class WeightPacker:
     def resolve(self, W):
         if not self.spec:
             return W
+        spec = getattr(self, '_spec_t', None)
+        if spec is None or len(spec) != len(self.spec):
+            spec = self._spec_t = _Spec(self.spec)
         if _needs_grad(self.srcs):
-            outs = _PackFn.apply(tuple(self.spec), *self.srcs)
+            outs = _PackFn.apply(spec, *self.srcs)
         else:
             with torch.no_grad():
-                outs = _PackFn.forward(_NoCtx(), tuple(self.spec), *self.srcs)
+                outs = _PackFn.forward(_NoCtx(), spec, *self.srcs)
         for k, v in W.items():
             if isinstance(v, WeightPacker._Lazy):
                 W[k] = outs[v.k]
