@@ -264,6 +264,8 @@ def pretrain_main(a, dtype, dev, rank, world):
         opt.step()
         last[task] = loss.detach()
 
+    # main thread + autograd thread on one core (before the first backward creates the engine thread): D.pin_step_threads
+    prev_mask = None if a.no_pin else D.pin_step_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -278,6 +280,8 @@ def pretrain_main(a, dtype, dev, rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prev_mask:
+        os.sched_setaffinity(0, prev_mask)          # the CPU baseline below wants all its threads
     if world > 1:
         tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -289,6 +293,7 @@ def pretrain_main(a, dtype, dev, rank, world):
                'unit': 'trajectories/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': 'BASELINE config[3]: R2R pre-training step, forward+backward+clip+AdamW, %s' % a.dtype, 'name': 'c4',
+                          'host_threads': 'main + autograd thread on their own free cores' if a.no_pin else 'main + autograd thread pinned to one core',
                           'trajectories_per_gpu': PT_B, 'txt_len': PT_L, 'trajectory_steps_total': nsteps, 'dropout': cfg.hidden_dropout_prob,
                           'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else
                                           'DDP x%d (rehearsal: gloo, gradient buckets staged through host memory)' % world) if world > 1 else 'single GPU'},
@@ -382,6 +387,7 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch kernels from Python each step instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pin', action='store_true', help='c4: do not pin the main / autograd threads to one core (A/B)')
     a = ap.parse_args()
 
     if a.gpus < 1:

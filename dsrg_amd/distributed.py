@@ -122,6 +122,25 @@ def wrap_model(model, device=None, bf16_grads=False, bucket_cap_mb=100, static_g
     return ddp
 
 
+def pin_step_threads(local_rank=0, local_world=1):
+    """Put the calling thread - and the autograd engine's device thread, if it is created afterwards (it inherits the mask) -
+    on ONE core of this process's allowed set, a different one per local rank.  A training step of this path is launch-bound
+    Python: the main thread and the engine thread never run at the same time, and when the scheduler places them on two cores
+    every forward -> backward -> optimizer hand-over pays a cross-core wake-up on cold caches (measured on the pre-training
+    step: 18.4 ms per step on two cores, 16.1 on one, same binary, same box).  Threads that already exist (RCCL / gloo
+    progress threads, created by init_process_group) keep their mask.  Returns the previous mask (restore with
+    os.sched_setaffinity(0, mask)), or None where the platform has no affinity call."""
+    if not hasattr(os, 'sched_getaffinity'):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) <= 1:
+        return set(allowed)
+    stride = max(1, len(allowed) // max(1, local_world))
+    core = allowed[(local_rank * stride + stride // 2) % len(allowed)]
+    os.sched_setaffinity(0, {core})
+    return set(allowed)
+
+
 def reduce_max(x, device='cpu'):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(x)
