@@ -24,16 +24,18 @@ def step(i):
     opt.step()
 for i in range(6): step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    for i in range(3): step(i)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(1)
 torch.cuda.synchronize()
-cnt = collections.Counter()
-for ev in prof.events():
-    for k in (ev.kernels or []):
-        if 'FillFunctor<float' in k.name or 'copyBuffer' in k.name or 'direct_copy' in k.name:
-            chain, e = [], ev
-            while e is not None and len(chain) < 4:
-                chain.append(e.name); e = e.cpu_parent
-            cnt[(k.name[:60], ' < '.join(chain), str(ev.input_shapes)[:50])] += 1
-for (kn, ch, shp), c in cnt.most_common(40):
-    print('%6.1f/step  %-60s %s %s' % (c / 3, kn, ch, shp))
+ks = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+ks.sort(key=lambda e: e.time_range.start)
+names = [e.name[:70] for e in ks]
+ctx = collections.Counter()
+for i, n in enumerate(names):
+    if 'FillFunctor<float' in n:
+        prev = next((names[j] for j in range(i - 1, -1, -1) if 'FillFunctor' not in names[j]), '?')
+        nxt = next((names[j] for j in range(i + 1, len(names)) if 'FillFunctor' not in names[j]), '?')
+        ctx[(prev[:60], nxt[:60])] += 1
+print('fills in one step:', sum(ctx.values()))
+for (a, b), c in ctx.most_common(15):
+    print('%4d  after %-60s before %s' % (c, a, b))
