@@ -86,7 +86,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + e
 // with K = 768 the FFN-in epilogue is otherwise VALU-bound (7-21 M erf per launch).
 __device__ __forceinline__ float gelu_erf_short(float x) {
   const float y = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, y, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, y, 1.0f));   // v_rcp_f32 (1 ulp), not the 11-instruction IEEE division
   float p = fmaf(t, 1.061405429f, -1.453152027f);
   p = fmaf(t, p, 1.421413741f);
   p = fmaf(t, p, -0.284496736f);

@@ -16,10 +16,15 @@
 #include "common.h"
 
 #ifdef DSRG_GEMM_STAMPS   // diagnostic build only (tools/gemm_stamps.py): per-workgroup s_memtime stamps of the tile's phases
-__device__ unsigned long long g_gemm_stamps[8192 * 5];
-#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_gemm_stamps[8192 * 8];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dsrg_debug_gemm_stamps(void* host_dst, int nbytes) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_stamps), nbytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int dsrg_debug_gemm_stamps_clear(void) {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gemm_stamps)) != hipSuccess) return -1;
+  return (int)hipMemset(p, 0, sizeof(g_gemm_stamps));
 }
 #else
 #define GEMM_STAMP(i) do {} while (0)
@@ -53,6 +58,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case DSRG_ACT_TANH: return tanhf(v);
     default: return v;
   }
+}
+// Epilogue specialisations (in-kernel stamps, tools/gemm_stamps.py): with the activation a run-time switch per ELEMENT the
+// row pass of the epilogue was ~35 scalar branches per 8 columns, 1100-1300 cycles per pass even with no activation at all
+// (a 128x128 tile: 10 k cycles of "rows out" against an 11 k-cycle K loop).  The common cases are therefore compiled as
+// straight-line code and chosen by ONE uniform branch per tile: ACT / RACT >= 0 are compile-time activations, -1 keeps the
+// run-time switch (ReLU / tanh heads and poolers, rare combinations).
+template <int ACT, bool SHORT_GELU>
+__device__ __forceinline__ float apply_act_c(float v, int act) {
+  if constexpr (ACT == DSRG_ACT_NONE) return v;
+  else if constexpr (ACT == DSRG_ACT_GELU) return SHORT_GELU ? gelu_erf_short(v) : gelu_erf(v);
+  else return apply_act<SHORT_GELU>(v, act);
+}
+template <int RACT>
+__device__ __forceinline__ float act_grad_c(float z, int res_act) {
+  if constexpr (RACT == DSRG_ACT_GELU) return act_grad(z, DSRG_ACT_GELU);
+  else return act_grad(z, res_act);
 }
 
 // FUSE: the LayerNorm-fusion epilogue (include/dsrg_hip.h, dsrg_gemm_problem_t): built for the 64x64 tile only, launched
@@ -477,9 +498,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       if (sg + 4 * j < P.r_np) { sr2.x += pr[j].x; sr2.y += pr[j].y; }
     }
   }
+  auto rows_out = [&](auto act_tag, auto ract_tag) {
+  constexpr int ACT = decltype(act_tag)::value, RACT = decltype(ract_tag)::value;   // -1: run-time (see apply_act_c)
 #pragma unroll
   for (int ep = 0; ep < EPASS; ++ep) {
     __syncthreads();                                // every wave is done reading the last stage / the previous image
+    GEMM_STAMP(5);
     if constexpr (FUSE) {
       lnpart[(0 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sa;
       lnpart[(1 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sr2;
@@ -496,6 +520,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       }
     }
     __syncthreads();
+    GEMM_STAMP(6);
     if (n < N && orow0 < RPP) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
@@ -513,6 +538,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
           const float ia = 1.0f / (float)K, ir = 1.0f / (float)N;
           msa.x = t0.x * ia; msa.y = rsqrtf(fmaxf(t0.y * ia - msa.x * msa.x, 0.f) + P.ln_eps);
           msr.x = t1.x * ir; msr.y = rsqrtf(fmaxf(t1.y * ir - msr.x * msr.x, 0.f) + P.ln_eps);
+          if (!P.a_stats) msa = make_float2(0.f, 1.f);          // one select per pass; the per-element code below has no branch
         }
         float v[CW];
 #pragma unroll
@@ -522,9 +548,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = a4[e];
-            if constexpr (FUSE) {
-              if (P.a_stats) x = msa.y * (x - msa.x * c1v[4 * h + e]);
-            }
+            if constexpr (FUSE) x = msa.y * (x - msa.x * c1v[4 * h + e]);     // no a_stats: msa = (0, 1), c1v = 0 -> x, exactly
             v[4 * h + e] = x + bv[4 * h + e];
           }
         }
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
           }
         }
 #pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = apply_act<sizeof(OutT) == 2>(v[e], act);
+        for (int e = 0; e < CW; ++e) v[e] = apply_act_c<ACT, sizeof(OutT) == 2>(v[e], act);
         if (vec) {
           if (Rp) {
             RawRes raw;
@@ -565,9 +589,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
                 for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - msr.x) * msr.y * rgv[e] + rbv[e];
               }
             }
-            if (res_act > 0) {
+            if (RACT > 0 || (RACT < 0 && res_act > 0)) {
 #pragma unroll
-              for (int e = 0; e < CW; ++e) v[e] *= act_grad(rv[e], res_act);
+              for (int e = 0; e < CW; ++e) v[e] *= act_grad_c<RACT>(rv[e], res_act);
             } else {
 #pragma unroll
               for (int e = 0; e < CW; ++e) v[e] += rv[e];
@@ -607,9 +631,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       }
     }
   }
+  };
+  using RT = std::integral_constant<int, -1>;
+  using A0 = std::integral_constant<int, DSRG_ACT_NONE>;
+  using AG = std::integral_constant<int, DSRG_ACT_GELU>;
+  // (the 8-wave tile with fp32 output keeps the run-time form only: with the copies its 128-register budget makes hipcc
+  // hand the K loop's scalar DMA bases to vector registers, which the asm statements cannot take)
+  constexpr bool SPEC = !(NWAVES == 8 && sizeof(OutT) == 4);
+  if (SPEC && res_act <= 0 && act == DSRG_ACT_NONE) rows_out(A0{}, A0{});
+  else if (SPEC && res_act <= 0 && act == DSRG_ACT_GELU) rows_out(AG{}, A0{});
+  else {
+    bool done = false;
+    if constexpr (TRANS != 0) {               // the dgrad of an FFN's second layer: (dY.W2) * gelu'(z)
+      if (res_act == DSRG_ACT_GELU && act == DSRG_ACT_NONE) { rows_out(A0{}, AG{}); done = true; }
+    }
+    if (!done) rows_out(RT{}, RT{});
+  }
   GEMM_STAMP(3);
 #ifdef DSRG_GEMM_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 8 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
 #endif
 }
 

@@ -16,7 +16,13 @@ SHAPES = [
     ('x.ff1 g+l N=3072 K=768 gelu', [(1280, 3072, 768), (2432, 3072, 768)], 1, False, False),
     ('x.ff2 g+l N=768 K=3072 f32+res', [(1280, 768, 3072), (2432, 768, 3072)], 0, True, True),
     ('pano.ff1 M=2304 N=3072 K=768 gelu', [(2304, 3072, 768)], 1, False, False),
+    ('g.ff1 M=1280 N=3072 K=768 gelu', [(1280, 3072, 768)], 1, False, False),
+    ('g.ff1 M=1280 N=3072 K=768 no act', [(1280, 3072, 768)], 0, False, False),
+    ('l.ff1 M=2432 N=3072 K=768 gelu', [(2432, 3072, 768)], 1, False, False),
+    ('l.qkv M=2432 N=2304 K=768', [(2432, 2304, 768)], 0, False, False),
 ]
+# --tiles: every shape is also run with these pinned tiles (dsrg_gemm_nt_tiled)
+TILES = [None, (64, 64, 3), (128, 128, 2), (128, 128, 3), (256, 128, 2), (256, 128, 3)] if '--tiles' in sys.argv else [None]
 
 
 def main():
@@ -24,7 +30,8 @@ def main():
     fn = lib.dsrg_debug_gemm_stamps
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
     dt = torch.bfloat16
-    for name, probs, act, of32, res in SHAPES:
+    for name in [(n_ + (' tile %dx%dx%d' % t_ if t_ else ''), p_, a_, o_, r_, t_) for (n_, p_, a_, o_, r_) in SHAPES for t_ in TILES]:
+        name, probs, act, of32, res, tile = name
         ps = []
         for (M, N, Kd) in probs:
             x = (torch.rand(M, Kd, device='cuda') * 2 - 1).to(dt)
@@ -34,14 +41,16 @@ def main():
             ps.append((x, w, b, r))
         outs = K.gemm(ps, act, of32)
         for _ in range(5):
-            K.gemm(ps, act, of32, outs=outs)
+            K.gemm(ps, act, of32, outs=outs, tile=tile)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); K.gemm(ps, act, of32, outs=outs); e1.record(); e1.synchronize()
+        assert lib.dsrg_debug_gemm_stamps_clear() == 0
+        torch.cuda.synchronize()
+        e0.record(); K.gemm(ps, act, of32, outs=outs, tile=tile); e1.record(); e1.synchronize()
         plan = K.gemm_plan(ps) if hasattr(K, 'gemm_plan') else None
-        buf = np.zeros(8192 * 5, np.uint64)
+        buf = np.zeros(8192 * 8, np.uint64)
         assert fn(buf.ctypes.data, buf.nbytes) == 0
-        st = buf.reshape(8192, 5)
+        st = buf.reshape(8192, 8)
         n = int((st[:, 3] > 0).sum())
         st = st[:n].astype(np.int64)
         t00 = st[:, 0].min()
@@ -51,6 +60,7 @@ def main():
         print('%-36s wgs %5d  event %.1f us  span %7d clk' % (name, n, e0.elapsed_time(e1) * 1e3, span))
         print('    start-after-first [10/50/90%%]: %s   end-before-last: %s' % (q(st[:, 0] - t00), q(st[:, 3].max() - st[:, 3])))
         print('    prologue %s | K loop %s | epilogue %s | total %s  (clk, 10/50/90%%)' % (q(ph[0]), q(ph[1]), q(ph[2]), q(st[:, 3] - st[:, 0])))
+        print('    epilogue split: wait-for-waves %s | image write + barrier %s | rows out %s' % (q(st[:, 5] - st[:, 2]), q(st[:, 6] - st[:, 5]), q(st[:, 3] - st[:, 6])))
         late = st[:, 0] - t00 > 0.3 * span
         print('    workgroups starting after 30%% of the span: %d (%.0f%%)' % (late.sum(), 100.0 * late.mean()))
 
