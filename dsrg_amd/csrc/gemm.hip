@@ -9,6 +9,7 @@
 // lane's 4 accumulator registers are 4 CONSECUTIVE output columns n of one row m: the epilogue then
 // reads bias/residual and writes C with 8/16-byte vector accesses.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #ifndef DSRG_ABLATE
 #define DSRG_ABLATE 0   // diagnostic builds: 1 = no LDS-DMA in the K loop, 2 = no fragment reads / MFMA
@@ -742,6 +743,28 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
   }
   bool fuse = false;
   for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out || a.p[i].trans;   // 64x64-only kernels
+  // Wide launches (every problem N >= 2304 and K <= 1024: packed QKV, FFN-in; 20 per nav-step): 128x128 with a 2-deep ring
+  // (64 KiB: two workgroups per CU) from 200 tiles on - r02t A/B in DESIGN.md section 4.0.  DSRG_GEMM_WIDE /
+  // DSRG_GEMM_LONGK (K >= 2048) = "BMxBNxNST:mintiles[,...]" override the candidates (tuning aid; first that reaches its
+  // minimum tile count wins, "0" = none).
+  {
+    int minN = 1 << 30, maxK = 0;
+    for (int i = 0; i < a.nprob; ++i) { minN = a.p[i].N < minN ? a.p[i].N : minN; maxK = a.p[i].K > maxK ? a.p[i].K : maxK; }
+    static const char* wide_env = getenv("DSRG_GEMM_WIDE");
+    static const char* longk_env = getenv("DSRG_GEMM_LONGK");
+    const char* e = nullptr;
+    if (!fuse && maxM > 64 && minN >= 2304 && maxK <= 1024) e = wide_env ? wide_env : "128x128x2:200";
+    else if (!fuse && maxM > 64 && minK >= 2048) e = longk_env;
+    while (e && *e) {
+      int tbm = 0, tbn = 0, tnst = 0, tmin = 0;
+      if (sscanf(e, "%dx%dx%d:%d", &tbm, &tbn, &tnst, &tmin) == 4) {
+        const TileShape* t = find_tile(tbm, tbn, bf16);
+        if (t && tile_has_nst(*t, tnst) && count_tiles(a, tbm, tbn) >= tmin) { bm = tbm; bn = tbn; nst = tnst; return count_tiles(a, bm, bn); }
+      }
+      const char* c = strchr(e, ',');
+      e = c ? c + 1 : nullptr;
+    }
+  }
   if (!fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000) {
     if (bf16) { bm = 256; bn = 128; nst = 3; } else { bm = 128; bn = 128; nst = 2; }
   } else {

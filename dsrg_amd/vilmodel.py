@@ -180,8 +180,13 @@ class GlocalTextPathNavCMT(nn.Module):
         self.split_branch_streams = os.environ.get('DSRG_SPLIT_BRANCHES', '1') == '1'     # global / local x-layers on two streams (3.6 % faster than grouped launches at R2R shapes; 0 = grouped)
         self.split_when_eager = False          # bench.py sets it to trace the captured schedule's launches eagerly
         self.split_max_ratio = float(os.environ.get('DSRG_SPLIT_MAX_RATIO', '4.0'))
-        # inference: the LayerNorms inside the x-layers are folded into the neighbouring GEMM epilogues (_x_layers_fused)
-        self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '1') == '1'
+        # inference: the LayerNorms inside the x-layers folded into the neighbouring GEMM epilogues (_x_layers_fused_gen).
+        # Off by default since r02t: with the specialised GEMM epilogue the plain kernels gained more than the FUSE ones
+        # (c2 step 1.180 ms unfused vs 1.197 fused), and only the plain kernels have the wide tiles (1.162)
+        self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '0') == '1'
+        # two-stream schedule: branches captured launch by launch in turn instead of one whole branch after the other
+        # (measured: no difference in the replayed graph, 1.1976 vs 1.1995 ms; off)
+        self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
         self._fold = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
@@ -602,8 +607,9 @@ class GlocalTextPathNavCMT(nn.Module):
             F[k] = (wf, wf.float().sum(1).contiguous(), (W[lin_key + '.b'] + w.float() @ b).contiguous())
         return F[k]
 
-    def _x_layers_fused(self, W, kv, txt_masks, feats, masks, dists, brs):
-        """_x_layers without its 3 LayerNorm launches per layer and branch (inference).  A post-LN sub-block leaves its
+    def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs):
+        """(generator: yields after every launch, returns the result - see _x_layers_gen)
+        _x_layers without its 3 LayerNorm launches per layer and branch (inference).  A post-LN sub-block leaves its
         UN-normalised sum y (compute dtype) plus per-row partial statistics written by the same GEMM launch; the projections
         that read LN(y) run on y with gamma folded into the weight and the mean / rstd correction in their epilogue, and the
         next dense + residual normalises its residual on the fly (dsrg_gemm_problem_t: stats_out / a_stats / r_stats).
@@ -645,32 +651,53 @@ class GlocalTextPathNavCMT(nn.Module):
         for i in range(nl):
             ks = ['x.%s.%d' % (b, i) for b in brs]
             q = proj('.cq')
+            yield
             offs = [((('g', 'l').index(brs[j]) * nl + i) * 2) * H for j in range(n)]
             a = Fn.attention_grouped([(q[j], kv[..., o:o + H], kv[..., o + H:o + 2 * H], txt_masks, None) for j, o in enumerate(offs)],
                                      nh, MASK_NEG10000)
+            yield
             st = new_stats()
             y = dense_res('.co', a, st)
+            yield
             cur = [(y[j], st[j], ks[j] + '.cln') for j in range(n)]
             qkv = proj('.qkv')
+            yield
             a = Fn.attention_grouped([(qkv[j][..., :H], qkv[j][..., H:2 * H], qkv[j][..., 2 * H:], masks[j],
                                        dists if brs[j] == 'g' else None) for j in range(n)], nh, MASK_NEG10000, sw, sb)
+            yield
             st = new_stats()
             y = dense_res('.so', a, st)
+            yield
             cur = [(y[j], st[j], ks[j] + '.sln') for j in range(n)]
             inter = proj('.ff1', ACT_GELU)
+            yield
             if i == nl - 1:
                 z = dense_res('.ff2', inter, None, out_f32=True)
+                yield
                 return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd)
             st = new_stats()
             y = dense_res('.ff2', inter, st)
+            yield
             cur = [(y[j], st[j], ks[j] + '.fln') for j in range(n)]
 
     def _x_layers(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
         """The CrossmodalEncoders of the branches in `brs` (global 'g', local 'l') in lock-step: every GEMM is one
         grouped launch over the branches (vilmodel.py:540-549, 454-469)."""
+        g = self._x_layers_gen(W, kv, txt_masks, feats, masks, dists, brs)
+        while True:
+            try:
+                next(g)
+            except StopIteration as e:
+                return e.value
+
+    def _x_layers_gen(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
+        """_x_layers as a generator that yields between its launches and returns the result: the two-stream schedule
+        (_x_layers_two_streams) advances the global and the local branch in turn, so that their nodes enter the captured HIP
+        graph interleaved - hipGraphLaunch submits kernel nodes in creation order, and a branch captured as a whole after the
+        other one starts several hundred microseconds late."""
         cfg = self.config
         if self.fuse_ln and not torch.is_grad_enabled() and not self.training and cfg.hidden_size % 64 == 0 and cfg.hidden_size <= 1024:
-            return self._x_layers_fused(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs)
+            return (yield from self._x_layers_fused_gen(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs))
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
@@ -681,12 +708,43 @@ class GlocalTextPathNavCMT(nn.Module):
             feats = Fn.attn_block_grouped([(feats[j], W[ks[j] + '.cq.w'], W[ks[j] + '.cq.b'], W[ks[j] + '.co.w'], W[ks[j] + '.co.b'], W[ks[j] + '.cln.g'],
                                             W[ks[j] + '.cln.b'], kvs[('g', 'l').index(brs[j]) * nl + i], txt_masks, None) for j in range(n)],
                                           nh, MASK_NEG10000, eps, self._attn_p(), ph)
+            yield
             feats = Fn.attn_block_grouped([(feats[j], W[ks[j] + '.qkv.w'], W[ks[j] + '.qkv.b'], W[ks[j] + '.so.w'], W[ks[j] + '.so.b'], W[ks[j] + '.sln.g'],
                                             W[ks[j] + '.sln.b'], None, masks[j], dists if brs[j] == 'g' else None) for j in range(n)],
                                           nh, MASK_NEG10000, eps, self._attn_p(), ph, sw, sb)
+            yield
             feats = Fn.ffn_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], W[ks[j] + '.ff2.w'], W[ks[j] + '.ff2.b'], feats[j],
                                      W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b']) for j in range(n)], eps, self.config.hidden_dropout_prob if self.training else 0.0)
+            yield
         return feats
+
+    def _x_layers_two_streams(self, W, kv, tm, g, v, gmask, vmask, dists):
+        """Global branch on the current stream, local branch on the side stream, advanced in turn (no-grad mode only)."""
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = {}
+        side = self._side_stream.get(cur.cuda_stream)
+        if side is None:
+            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
+        side.wait_stream(cur)
+        gens = [(side, self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',))),
+                (cur, self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',)))]
+        res, live = [None, None], [0, 1]
+        self._fork_depth += 1
+        try:
+            while live:
+                for i in list(live):
+                    with torch.cuda.stream(gens[i][0]):
+                        try:
+                            next(gens[i][1])
+                        except StopIteration as e:
+                            res[i] = e.value[0]
+                            live.remove(i)
+        finally:
+            self._fork_depth -= 1
+        cur.wait_stream(side)
+        res[0].record_stream(cur)
+        return res[1], res[0]
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
         p = self.config.hidden_dropout_prob if self.training else 0.0
@@ -744,9 +802,12 @@ class GlocalTextPathNavCMT(nn.Module):
         # of the split schedule cost 3 %)
         if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
                 and max(G, Vp) <= self.split_max_ratio * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
-            lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
-            g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
-            v = lj()
+            if self.interleave_branches:
+                g, v = self._x_layers_two_streams(W, kv, tm, g, v, gmap_masks.contiguous(), vp_masks.contiguous(), dists)
+            else:
+                lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
+                g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
+                v = lj()
         else:
             g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
 
