@@ -110,18 +110,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
   }
-  int g = 0;
+  // The launch record comes in through scalar loads from the kernarg segment, 300-500+ cycles each when they miss.  Left to
+  // the compiler they are sunk to their first uses: 7 dependent load -> wait round trips before the first DMA could be
+  // issued (in-kernel stamps: 2500-5300 cycles from kernel entry to the first stage, a third of a 64x64 tile's lifetime).
+  // So: everything at a fixed offset (tile starts, panel widths, problem 0) is read in ONE batch at entry - the asm
+  // statements below only pin the values into SGPRs at that point - and only the workgroups of problems 1.. pay a second
+  // batch.  tile_start[] past the last problem is INT_MAX (host), so the search needs no problem count.
+  int g = 0, tstart = 0, PW = args.pw[0];
 #pragma unroll
   for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
-    if (i < args.nprob && bid >= args.tile_start[i]) g = i;
-  const dsrg_gemm_problem_t& P = args.p[g];
+    if (bid >= args.tile_start[i]) { g = i; tstart = args.tile_start[i]; PW = args.pw[i]; }
+  dsrg_gemm_problem_t P = args.p[0];
+#define DSRG_PIN_PROBLEM(P_)                                                                                                        \
+  do {                                                                                                                              \
+    asm volatile("" ::"s"(P_.A), "s"(P_.W), "s"(P_.bias), "s"(P_.residual), "s"(P_.C), "s"(P_.M), "s"(P_.N), "s"(P_.K), "s"(P_.lda), \
+                 "s"(P_.ldw), "s"(P_.ldr), "s"(P_.ldc), "s"(P_.c_pre), "s"(P_.ldcp), "s"(P_.res_act), "s"(P_.a_colsum));              \
+    if constexpr (FUSE)                                                                                                             \
+      asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out),          \
+                   "s"(P_.a_np), "s"(P_.r_np), "s"(P_.ln_eps));                                                                      \
+  } while (0)
+  DSRG_PIN_PROBLEM(P);
+  if (g != 0) {
+    P = args.p[g];
+    DSRG_PIN_PROBLEM(P);
+  }
+#undef DSRG_PIN_PROBLEM
   const int M = P.M, N = P.N, K = P.K;
-  const int t = bid - args.tile_start[g];
+  const int t = bid - tstart;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   // Walk: N-panels of PW tiles (outermost), inside a panel super-rows of GM M-tiles, inside a super-row N, then M
   // fastest.  The ~T/8 consecutive tiles one XCD runs then cover a compact (T/8/PW) x PW patch of the tile grid whose
   // A rows + W rows fit that XCD's 4 MiB L2 (PW is chosen on the host for that), instead of a stripe that needs all of W.
-  const int GM = args.gm, PW = args.pw[g];
+  const int GM = args.gm;
   const int full = tiles_m * PW;                        // tiles in a full panel
   const int pnl = t / full, in_pnl = t - pnl * full;
   const int wn_p = min(PW, tiles_n - pnl * PW);         // width of this (possibly narrower, last) panel
@@ -702,7 +722,7 @@ int count_tiles(GemmArgs& a, int m, int n) {
     a.tile_start[i] = tot;
     tot += ((a.p[i].M + m - 1) / m) * ((a.p[i].N + n - 1) / n);
   }
-  a.tile_start[a.nprob] = tot;
+  for (int i = a.nprob; i <= DSRG_MAX_GROUPS; ++i) a.tile_start[i] = i == a.nprob ? tot : 0x7fffffff;   // (the kernel's problem search)
   return tot;
 }
 
