@@ -543,6 +543,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     __syncthreads();
     GEMM_STAMP(6);
     if (n < N && orow0 < RPP) {
+      // the image chunks of all passes are read up front (unconditionally: rows clamped into the image), so that the passes'
+      // LDS latencies overlap - the early exit below otherwise keeps every pass's read behind the previous pass's branch
+      constexpr int NCH = CW / 4;
+      constexpr bool PRE_IMG = !FUSE && NPASS * NCH <= 16 && NWAVES <= 4;
+      f32x4 img[PRE_IMG ? NPASS : 1][NCH];
+      if constexpr (PRE_IMG) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int rr = min(orow0 + ps * RPP, EROWS - 1);
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) img[ps][h] = *reinterpret_cast<const f32x4*>(cimg + rr * BN + (((oc * NCH + h) ^ (rr & 7)) << 2));
+        }
+      }
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int r = orow0 + ps * RPP;
@@ -565,7 +578,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
         for (int h = 0; h < CW / 4; ++h) {
           const int ch = oc * (CW / 4) + h;           // 4-float chunk of the image row
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((ch ^ (r & 7)) << 2));
+          f32x4 a4;
+          if constexpr (PRE_IMG) a4 = img[ps][h];
+          else a4 = *reinterpret_cast<const f32x4*>(cimg + r * BN + ((ch ^ (r & 7)) << 2));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = a4[e];
