@@ -35,12 +35,26 @@ struct AttnGroup {
   int start[DSRG_ATTN_MAX_GROUPS + 1];
   int n;
 };
+// The problem record is read from the kernarg segment in ONE batch of scalar loads at kernel entry (problem 0 sits at fixed
+// offsets; the empty asm statement pins the values into SGPRs there) instead of a chain of dependent load -> wait round
+// trips sunk to the first uses (9 in the forward kernel's ISA); only workgroups of problems 1.. pay a second batch.
+// start[] past the last problem is INT_MAX (host), so the search needs no problem count.  Same scheme as gemm.hip.
+#define ATTN_PIN_PROBLEM(a_)                                                                                                   \
+  asm volatile("" ::"s"(a_.Q), "s"(a_.K), "s"(a_.V), "s"(a_.O), "s"(a_.q_bs), "s"(a_.k_bs), "s"(a_.v_bs), "s"(a_.o_bs),         \
+               "s"(a_.q_rs), "s"(a_.k_rs), "s"(a_.v_rs), "s"(a_.o_rs), "s"(a_.kmask), "s"(a_.mask_mode), "s"(a_.dists),          \
+               "s"(a_.sprel_w), "s"(a_.sprel_b), "s"(a_.Nq), "s"(a_.Nk), "s"(a_.scale), "s"(a_.lse), "s"(a_.NH), "s"(a_.p_drop), \
+               "s"(a_.seed))
 #define ATTN_PICK_PROBLEM(grp)                                   \
-  int gsel = 0;                                                  \
+  int gsel = 0, gstart = 0;                                      \
   _Pragma("unroll") for (int i_ = 1; i_ < DSRG_ATTN_MAX_GROUPS; ++i_) \
-    if (i_ < grp.n && (int)blockIdx.x >= grp.start[i_]) gsel = i_;    \
-  const AttnArgs& a = grp.a[gsel];                               \
-  const int bx = (int)blockIdx.x - grp.start[gsel];
+    if ((int)blockIdx.x >= grp.start[i_]) { gsel = i_; gstart = grp.start[i_]; } \
+  AttnArgs a = grp.a[0];                                         \
+  ATTN_PIN_PROBLEM(a);                                           \
+  if (gsel != 0) {                                               \
+    a = grp.a[gsel];                                             \
+    ATTN_PIN_PROBLEM(a);                                         \
+  }                                                              \
+  const int bx = (int)blockIdx.x - gstart;
 
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
@@ -1018,6 +1032,7 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
   int blocks = 0;
   for (int i = 0; i < grp.n; ++i) { grp.start[i] = blocks; blocks += (grp.a[i].Nq + qpb - 1) / qpb; }
   grp.start[grp.n] = blocks;
+  for (int i = grp.n + 1; i <= DSRG_ATTN_MAX_GROUPS; ++i) grp.start[i] = 0x7fffffff;      // (the kernels' problem search)
   dim3 grid(blocks, NH, B), block(256);
   const bool drop = p_drop > 0.f;      // the dropout variants are separate instantiations: the inference kernels carry none of it
   hipStream_t st = (hipStream_t)stream;
