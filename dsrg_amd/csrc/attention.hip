@@ -45,11 +45,11 @@ struct AttnGroup {
                "s"(a_.sprel_w), "s"(a_.sprel_b), "s"(a_.Nq), "s"(a_.Nk), "s"(a_.scale), "s"(a_.lse), "s"(a_.NH), "s"(a_.p_drop), \
                "s"(a_.seed))
 #define ATTN_PICK_PROBLEM(grp)                                   \
+  AttnArgs a = grp.a[0];                                         \
+  ATTN_PIN_PROBLEM(a);                                           \
   int gsel = 0, gstart = 0;                                      \
   _Pragma("unroll") for (int i_ = 1; i_ < DSRG_ATTN_MAX_GROUPS; ++i_) \
     if ((int)blockIdx.x >= grp.start[i_]) { gsel = i_; gstart = grp.start[i_]; } \
-  AttnArgs a = grp.a[0];                                         \
-  ATTN_PIN_PROBLEM(a);                                           \
   if (gsel != 0) {                                               \
     a = grp.a[gsel];                                             \
     ATTN_PIN_PROBLEM(a);                                         \

@@ -116,10 +116,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   // So: everything at a fixed offset (tile starts, panel widths, problem 0) is read in ONE batch at entry - the asm
   // statements below only pin the values into SGPRs at that point - and only the workgroups of problems 1.. pay a second
   // batch.  tile_start[] past the last problem is INT_MAX (host), so the search needs no problem count.
-  int g = 0, tstart = 0, PW = args.pw[0];
-#pragma unroll
-  for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
-    if (bid >= args.tile_start[i]) { g = i; tstart = args.tile_start[i]; PW = args.pw[i]; }
   dsrg_gemm_problem_t P = args.p[0];
 #define DSRG_PIN_PROBLEM(P_)                                                                                                        \
   do {                                                                                                                              \
@@ -129,7 +125,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out),          \
                    "s"(P_.a_np), "s"(P_.r_np), "s"(P_.ln_eps));                                                                      \
   } while (0)
-  DSRG_PIN_PROBLEM(P);
+  DSRG_PIN_PROBLEM(P);                      // (in front of the search: its loads go out with the tile starts')
+  int g = 0, tstart = 0, PW = args.pw[0];
+#pragma unroll
+  for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
+    if (bid >= args.tile_start[i]) { g = i; tstart = args.tile_start[i]; PW = args.pw[i]; }
   if (g != 0) {
     P = args.p[g];
     DSRG_PIN_PROBLEM(P);

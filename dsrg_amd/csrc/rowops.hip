@@ -64,12 +64,19 @@ struct LnArgs {
 template <typename TI, typename TO, int NV, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   const int lane = threadIdx.x & 63;
-  int g = 0;
+  // problem record in one batch of scalar loads at entry (problem 0 at fixed offsets, pinned into SGPRs; blk_start[] is
+  // INT_MAX past the last problem) - see gemm.hip: the compiler otherwise chains three dependent load -> wait round trips
+  dsrg_ln_problem_t P = a.p[0];
+  asm volatile("" ::"s"(P.x), "s"(P.residual), "s"(P.gamma), "s"(P.beta), "s"(P.out), "s"(P.M), "s"(P.ldx), "s"(P.ldr), "s"(P.ldo), "s"(a.H), "s"(a.eps));
+  int g = 0, bstart = 0;
 #pragma unroll
   for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
-    if (i < a.nprob && (int)blockIdx.x >= a.blk_start[i]) g = i;
-  const dsrg_ln_problem_t& P = a.p[g];
-  const int row = ((int)blockIdx.x - a.blk_start[g]) * WPB + (threadIdx.x >> 6);
+    if ((int)blockIdx.x >= a.blk_start[i]) { g = i; bstart = a.blk_start[i]; }
+  if (g != 0) {
+    P = a.p[g];
+    asm volatile("" ::"s"(P.x), "s"(P.residual), "s"(P.gamma), "s"(P.beta), "s"(P.out), "s"(P.M), "s"(P.ldx), "s"(P.ldr), "s"(P.ldo));
+  }
+  const int row = ((int)blockIdx.x - bstart) * WPB + (threadIdx.x >> 6);
   if (row >= P.M) return;
   const TI* __restrict__ x = reinterpret_cast<const TI*>(P.x) + (size_t)row * P.ldx;
   const TO* __restrict__ res = reinterpret_cast<const TO*>(P.residual);
@@ -150,6 +157,10 @@ constexpr int EWAVES = 16;
 template <typename T>
 __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float WT[];
+  // the whole launch record in one batch of scalar loads (the compiler otherwise sinks them into four dependent rounds)
+  asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
+               "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
+               "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H, nv = (H + 255) / 256, HS = H + 4;
   const int row = blockIdx.x * EWAVES + wave;
@@ -590,6 +601,7 @@ static int layernorm_fwd_impl(const dsrg_ln_problem_t* problems, int nproblems, 
   }
   if (a.nprob == 0) return DSRG_OK;
   a.blk_start[a.nprob] = blocks;
+  for (int i = a.nprob + 1; i <= DSRG_MAX_GROUPS; ++i) a.blk_start[i] = 0x7fffffff;     // (the kernel's problem search)
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(blocks), block(256);
 #define DSRG_LN_LAUNCH(NV_)                                                                                              \
