@@ -788,7 +788,9 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     static const char* wide_env = getenv("DSRG_GEMM_WIDE");
     static const char* longk_env = getenv("DSRG_GEMM_LONGK");
     const char* e = nullptr;
-    if (!fuse && maxM > 64 && minN >= 2304 && maxK <= 1024) e = wide_env ? wide_env : (bf16 ? "128x128x2:200" : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
+    const bool big = !fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000;      // the 8-wave 256x128 tile below
+    if (big) e = nullptr;
+    else if (!fuse && maxM > 64 && minN >= 2304 && maxK <= 1024) e = wide_env ? wide_env : (bf16 ? "128x128x2:200" : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
     else if (!fuse && maxM > 64 && minK >= 2048) e = longk_env ? longk_env : "128x64x4:1";    // FFN-out: 1.136 -> 1.128 ms per c2 step
     else if (!fuse && maxM > 64 && maxK <= 1024) { static const char* narrow_env = getenv("DSRG_GEMM_NARROW"); e = narrow_env; }
     while (e && *e) {

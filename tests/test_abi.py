@@ -40,8 +40,10 @@ def test_argument_validation_without_gpu():
 
 def test_gemm_plan_and_tile_validation_without_gpu():
     """dsrg_gemm_nt_plan is a host-only query and dsrg_gemm_nt_tiled validates its tile before any launch: the nav-step
-    shapes get the 64x64 tile with a 3-deep ring (2-deep above 1024 tiles), the once-per-episode text K/V panel the 8-wave
-    256x128 tile (bf16 only), a LayerNorm-fusion problem always the 64-column tile, and a tile that is not built is EINVAL."""
+    N = 768 shapes get the 64x64 tile with a 3-deep ring, the wide ones (packed QKV, FFN-in) 128x128 with a 2-deep ring (bf16;
+    fp32: 64x64, 2-deep above 1024 tiles), FFN-out (K >= 2048) 128x64 with a 4-deep ring, the once-per-episode text K/V panel
+    the 8-wave 256x128 tile (bf16 only), a LayerNorm-fusion problem always the 64-column tile, and a tile that is not built is
+    EINVAL."""
     import ctypes as C
     from dsrg_amd import _lib
     lib = _lib.load()
@@ -55,7 +57,10 @@ def test_gemm_plan_and_tile_validation_without_gpu():
         assert lib.dsrg_gemm_nt_plan(arr, 1, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst)) == 0
         return bm.value, bn.value, nst.value, nt.value
     assert plan(2432, 768, 768) == (64, 64, 3, 38 * 12)
-    assert plan(2432, 2304, 768) == (64, 64, 2, 38 * 36)
+    assert plan(2432, 2304, 768) == (128, 128, 2, 19 * 18)
+    assert plan(2432, 2304, 768, _lib.F32) == (64, 64, 2, 38 * 36)
+    assert plan(2432, 768, 3072) == (128, 64, 4, 19 * 12)
+    assert plan(2432, 2304, 768, a_stats=16)[:2] == (64, 64)
     assert plan(5120, 12288, 768) == (256, 128, 3, 20 * 96)
     assert plan(5120, 12288, 768, _lib.F32)[:3] == (128, 128, 2)
     assert plan(5120, 12288, 768, stats_out=16)[:2] == (64, 64)
