@@ -604,8 +604,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
             }
           }
         }
+        if constexpr (ACT == DSRG_ACT_GELU && sizeof(OutT) == 2) {
 #pragma unroll
-        for (int e = 0; e < CW; ++e) v[e] = apply_act_c<ACT, sizeof(OutT) == 2>(v[e], act);
+          for (int e = 0; e < CW; e += 2) {
+            const f32x2_t g2 = gelu_erf_short2(f32x2_t{v[e], v[e + 1]});
+            v[e] = g2.x; v[e + 1] = g2.y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) v[e] = apply_act_c<ACT, sizeof(OutT) == 2>(v[e], act);
+        }
         if (vec) {
           if (Rp) {
             RawRes raw;
