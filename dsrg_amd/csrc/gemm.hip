@@ -825,7 +825,7 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
   int bm, bn, nst;
   const int tiles = plan_tiles(a, bm, bn, nst, sizeof(T) == 2, fbm, fbn, fnst);
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
-  a.gm = gm_env ? atoi(gm_env) : 4;
+  a.gm = gm_env ? atoi(gm_env) : (bm >= 128 ? 1 : 2);      // r02w A/B, c2 step: 4 everywhere 1.0847 ms | 2 everywhere 1.0816 | 1 everywhere 1.0803 | 8: 1.099
   if (a.gm < 1) a.gm = 1;
   static const char* np_env = getenv("DSRG_GEMM_NP");      // tuning aid: force the number of N-panels (1 = stripes)
   static const char* nt_env = getenv("DSRG_GEMM_NT");      // tuning aid: 0/1 non-temporal C stores
