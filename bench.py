@@ -282,10 +282,9 @@ def pretrain_main(a, dtype, dev, rank, world):
     dt = time.perf_counter() - t0
     if prev_mask:
         os.sched_setaffinity(0, prev_mask)          # the CPU baseline below wants all its threads
+    evidence = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, evidence = rank_evidence(dt, dev, world)
     assert all(torch.isfinite(v) for v in last.values()), 'non-finite pre-training loss'
     if rank == 0:
         nsteps = {t: int(batches[t]['traj_view_img_fts'].shape[0]) for t in PT_TASKS}
@@ -298,6 +297,9 @@ def pretrain_main(a, dtype, dev, rank, world):
                           'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else
                                           'DDP x%d (rehearsal: gloo, gradient buckets staged through host memory)' % world) if world > 1 else 'single GPU'},
                'final_losses': {t: float(v) for t, v in last.items()}}
+        if evidence:
+            out['ranks_seen'], out['backend'] = evidence['ranks_seen'], evidence['backend']
+            out['per_rank_ms'] = [t / a.steps * 1e3 for t in evidence['per_rank_s']]
         if not a.no_roofline:
             # DDP hooks must not fire during the replayed step: run it on the bare module
             def one_step():
@@ -335,6 +337,20 @@ def pretrain_cpu_baseline(cfg, sd, budget_s=25.0):
             'sample': '%d forward+backward steps of %d trajectories (no optimiser step, fp32, %d threads), %.1f s' % (it, Bc, cores, dt)}
 
 
+def rank_evidence(dt, dev, world):
+    """What the live backend saw (N > 1): ranks_seen = an all-reduce of ones, per_rank_ms = an all-gather of every rank's
+    own timed-region wall time; returns (max over ranks, fields for the JSON line)."""
+    on_dev = dist.get_backend() == 'nccl'
+    d = dev if on_dev else 'cpu'
+    ones = torch.ones(1, device=d, dtype=torch.float64)
+    dist.all_reduce(ones)
+    mine = torch.tensor([dt], device=d, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per = [float(t.item()) for t in every]
+    return max(per), {'ranks_seen': int(round(float(ones.item()))), 'backend': dist.get_backend(), 'per_rank_s': per}
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -342,26 +358,61 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what `python -m torch.distributed.run --nproc-per-node N` would do;
     the reference launches its ranks the same way, pretrain_src/run_r2r.sh:8-15).  The parent never touches the GPU;
-    rank 0's stdout (the one JSON line) is forwarded; any failing child fails the run."""
-    import subprocess
+    rank 0's stdout (the one JSON line) is forwarded.  Fail fast: every child is polled; as soon as one exits non-zero
+    the others are terminated (a rank that died before a barrier would otherwise leave its peers waiting in RCCL until the
+    driver's time limit) and the parent exits non-zero; an overall time limit (DSRG_BENCH_SPAWN_TIMEOUT seconds, default
+    1500) does the same.  Children are always fresh processes - nothing that touched a GPU is ever re-exec'ed."""
+    import subprocess, tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('DSRG_BENCH_SPAWN_TIMEOUT', '1500'))
     env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT') or str(_free_port()),
                LOCAL_WORLD_SIZE=str(n))
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     procs = []
+    out0 = tempfile.TemporaryFile()               # rank 0's stdout: a file, so that polling never blocks on a full pipe
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t0, why = time.monotonic(), None
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                why = 'rank %d exited with code %d' % bad[0]
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if time.monotonic() - t0 > timeout_s:
+                why = 'no result after %.0f s' % timeout_s
+                break
+            time.sleep(0.05)
+    finally:
+        if why is not None or any(p.poll() is None for p in procs):
+            stop_all()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit('bench.py: rank exit codes %s' % rcs)
+    if why is not None:
+        raise SystemExit('bench.py: %s; remaining ranks stopped (exit codes %s)' % (why, [p.returncode for p in procs]))
 
 
 def spawn_selftest(rank, world):
@@ -371,6 +422,11 @@ def spawn_selftest(rank, world):
     t = torch.ones(1)
     dist.all_reduce(t)
     assert int(t.item()) == world
+    die = os.environ.get('DSRG_BENCH_SELFTEST_DIE_RANK')
+    if die is not None and int(die) == rank:          # test hook: this rank dies mid-run, its peers wait in the next collective
+        os._exit(17)
+    if die is not None:
+        time.sleep(1.0)
     if rank == 0:
         print(json.dumps({'selftest': True, 'n_gpus': world, 'ranks_seen': int(t.item())}), flush=True)
     dist.barrier()
@@ -448,10 +504,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    evidence = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, evidence = rank_evidence(dt, dev, world)
     fused = runner.out['fused_logits']
     assert torch.isfinite(fused).any(1).all(), 'bench produced no finite logits'
 
@@ -472,6 +527,9 @@ def main():
             'whole_step_tflops': world * B * a.steps * fl / dt / 1e12,
             'whole_step_frac_of_mfma_peak': B * a.steps * fl / dt / (MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32),
         }
+        if evidence:
+            out['ranks_seen'], out['backend'] = evidence['ranks_seen'], evidence['backend']
+            out['per_rank_ms'] = [t / a.steps * 1e3 for t in evidence['per_rank_s']]
         # language mode runs once per episode, outside the nav-step metric (SURVEY 8d asks for it separately): eager launches
         l0 = T(lbs[0], dev)
         with torch.no_grad():

@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class HeadTailProblem(C.Structure):

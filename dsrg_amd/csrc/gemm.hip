@@ -51,6 +51,20 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 // banks, so the pair index is XORed with (row bit 1, row bit 3): the 8 rows then cover 8 different 32-byte bank groups.
 __device__ __forceinline__ int swt(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
 
+// Sum over groups of L (8 or 16) consecutive lanes, every lane of a group receiving the total: DPP moves inside a row of 16
+// lanes (xor 1, xor 2 by quad_perm; the two quads of an 8-lane half by row_half_mirror; the halves by row_mirror) instead of
+// ds_bpermute round trips.  Lanes that are switched off contribute 0 (bound_ctrl).
+template <int L>
+__device__ __forceinline__ float dpp_group_sum(float v) {
+  static_assert(L == 8 || L == 16, "8 or 16 lanes");
+  auto mv = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true)); };
+  v += mv(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+  v += mv(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+  v += mv(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+  if constexpr (L == 16) v += mv(v, std::integral_constant<int, 0x140>{});     // row_mirror
+  return v;
+}
+
 template <bool SHORT_GELU>
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -77,8 +91,15 @@ __device__ __forceinline__ float act_grad_c(float z, int res_act) {
   else return act_grad(z, res_act);
 }
 
-// FUSE: the LayerNorm-fusion epilogue (include/dsrg_hip.h, dsrg_gemm_problem_t): built for the 64x64 tile only, launched
-// only when a problem of the group asks for it, so the plain kernels carry none of its registers.
+// FUSE: the LayerNorm-fusion epilogue (include/dsrg_hip.h, dsrg_gemm_problem_t), launched only when a problem of the group
+// asks for it, so the plain kernels carry none of its registers.  Two kinds, so that each carries only its own operands:
+//   FUSE_A  (1): the A operand is an un-normalised row y with partial statistics (a_stats): the projections that read LN(y);
+//   FUSE_RS (2): the residual is un-normalised (r_stats) and / or the launch writes the partial statistics of what it stores
+//                (stats_out): the dense + residual launches that produce the next y.
+// Partial statistics are float2 (sum, sum of squares) per row and 64-column block, stored BLOCK-major ([N/64][M]) so that a
+// wave's loads and stores of one block are contiguous (round 3 stamps, profiles/r03a_gemm_stamps_fuse.txt: with the row-major
+// layout every partial load touched 64 lines, 1100-1700 cycles of prologue in front of the first stage).
+constexpr int FUSE_NONE = 0, FUSE_A = 1, FUSE_RS = 2;
 // WAVES_M x WAVES_N waves (2x2 = 256 threads for every tile but the 256x128 one, which runs 4x2 = 512 threads: two waves
 // per SIMD of 64x64 each, so that a workgroup that owns its CU still has a second wave per SIMD to issue LDS reads and
 // DMAs while the first one's MFMAs run).
@@ -87,11 +108,11 @@ __device__ __forceinline__ float act_grad_c(float z, int res_act) {
 // output columns (again 128-byte rows, the same DMA pieces); its MFMA fragments come out of LDS through the gfx950
 // transposing read ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group, two reads = the 8 k values a lane holds),
 // so dX = dY.W (TRANS 2) and dW = dY^T.X (TRANS 3) need no transposed copy of W, dY or X in HBM.
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
+template <typename T, typename OutT, int BM, int BN, int NST, int FUSE = 0, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const GemmArgs args) {
   GEMM_STAMP(0);
   constexpr bool TA = (TRANS & 1) != 0, TW = (TRANS & 2) != 0;
-  static_assert(TRANS == 0 || (BM == 64 && BN == 64 && sizeof(T) == 2 && !FUSE), "transposed operands: bf16, 64x64 tile");
+  static_assert(TRANS == 0 || (BM == 64 && BN == 64 && sizeof(T) == 2 && FUSE == 0), "transposed operands: bf16, 64x64 tile");
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
@@ -121,9 +142,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   do {                                                                                                                              \
     asm volatile("" ::"s"(P_.A), "s"(P_.W), "s"(P_.bias), "s"(P_.residual), "s"(P_.C), "s"(P_.M), "s"(P_.N), "s"(P_.K), "s"(P_.lda), \
                  "s"(P_.ldw), "s"(P_.ldr), "s"(P_.ldc), "s"(P_.c_pre), "s"(P_.ldcp), "s"(P_.res_act), "s"(P_.a_colsum));              \
-    if constexpr (FUSE)                                                                                                             \
-      asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out),          \
-                   "s"(P_.a_np), "s"(P_.r_np), "s"(P_.ln_eps));                                                                      \
+    if constexpr (FUSE == FUSE_A) asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.a_np), "s"(P_.ln_eps));                   \
+    if constexpr (FUSE == FUSE_RS)                                                                                                  \
+      asm volatile("" ::"s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out), "s"(P_.r_np), "s"(P_.ln_eps));          \
   } while (0)
   DSRG_PIN_PROBLEM(P);                      // (in front of the search: its loads go out with the tile starts')
   int g = 0, tstart = 0, PW = args.pw[0];
@@ -191,40 +212,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     }
   }
 
-  // ---- FUSE: this thread's share of the LayerNorm partials of its tile's rows (row = tid % BM, every 4th partial from
-  // tid / BM on), issued here with everything else that can hide behind the first stage; they are summed after the K loop.
-  constexpr int SP = 4;                               // partial loads per thread and set: a_np, r_np <= 16
-  float2 pa[FUSE ? SP : 1], pr[FUSE ? SP : 1];
-  if constexpr (FUSE) {
-    static_assert(BM == 64, "the fused epilogue assumes 4 threads per tile row");
-    const int srow = min(m0 + (tid & (BM - 1)), M - 1), sg = tid / BM;
+  // ---- FUSE: this thread's share of the LayerNorm partials of its tile's rows (row = tid % BM, every TG-th partial from
+  // tid / BM on), issued here with everything else that can hide behind the first stage (block-major table: a wave's 64
+  // rows of one block are 512 contiguous bytes); they are summed after the K loop.
+  constexpr int TG = THREADS / BM > 0 ? THREADS / BM : 1;     // threads per tile row (4 at BM = 64, 2 at BM = 128)
+  constexpr int SP = 16 / TG;                                 // partial loads per thread: a_np, r_np <= 16
+  float2 pl[FUSE ? SP : 1];
+  const float* __restrict__ stp = nullptr;
+  int snp = 1;
+  if constexpr (FUSE == FUSE_A) { stp = P.a_stats; snp = P.a_np; }
+  if constexpr (FUSE == FUSE_RS) { stp = P.r_stats; snp = P.r_np; }
+  if constexpr (FUSE != 0) {
+    static_assert(THREADS % BM == 0 && TG * SP == 16, "the fused epilogue sums 16 / TG partials per thread");
+    const int srow = min(m0 + (tid % BM), M - 1), sg = tid / BM;
 #pragma unroll
-    for (int j = 0; j < SP; ++j) { pa[j] = make_float2(0.f, 0.f); pr[j] = make_float2(0.f, 0.f); }
-    if (P.a_stats) {
-      const float2* ps_ = reinterpret_cast<const float2*>(P.a_stats) + (size_t)srow * P.a_np;
+    for (int j = 0; j < SP; ++j) pl[j] = make_float2(0.f, 0.f);
+    if (stp) {
+      const float2* ps_ = reinterpret_cast<const float2*>(stp) + srow;
 #pragma unroll
-      for (int j = 0; j < SP; ++j) pa[j] = ps_[min(sg + 4 * j, P.a_np - 1)];
-    }
-    if (P.r_stats) {
-      const float2* ps_ = reinterpret_cast<const float2*>(P.r_stats) + (size_t)srow * P.r_np;
-#pragma unroll
-      for (int j = 0; j < SP; ++j) pr[j] = ps_[min(sg + 4 * j, P.r_np - 1)];
+      for (int j = 0; j < SP; ++j) pl[j] = ps_[(size_t)min(sg + TG * j, snp - 1) * M];
     }
   }
   // ... and the per-column vectors of this thread's CW output columns (row sums of the folded weight; residual gamma / beta)
-  float c1v[FUSE ? CW : 1], rgv[FUSE ? CW : 1], rbv[FUSE ? CW : 1];
-  if constexpr (FUSE) {
+  float c1v[FUSE == FUSE_A ? CW : 1], rgv[FUSE == FUSE_RS ? CW : 1], rbv[FUSE == FUSE_RS ? CW : 1];
+  if constexpr (FUSE == FUSE_A) {
 #pragma unroll
-    for (int e = 0; e < CW; ++e) { c1v[e] = 0.f; rgv[e] = 1.f; rbv[e] = 0.f; }
-    if (n + CW - 1 < N) {
+    for (int e = 0; e < CW; ++e) c1v[e] = 0.f;
+    if (stp && n + CW - 1 < N) {
 #pragma unroll
       for (int h = 0; h < CW / 4; ++h) {
-        if (P.a_stats) { const float4 t4 = *reinterpret_cast<const float4*>(P.a_c1 + n + 4 * h); c1v[4 * h] = t4.x; c1v[4 * h + 1] = t4.y; c1v[4 * h + 2] = t4.z; c1v[4 * h + 3] = t4.w; }
-        if (P.r_stats) {
-          const float4 g4 = *reinterpret_cast<const float4*>(P.r_gamma + n + 4 * h), b4 = *reinterpret_cast<const float4*>(P.r_beta + n + 4 * h);
-          rgv[4 * h] = g4.x; rgv[4 * h + 1] = g4.y; rgv[4 * h + 2] = g4.z; rgv[4 * h + 3] = g4.w;
-          rbv[4 * h] = b4.x; rbv[4 * h + 1] = b4.y; rbv[4 * h + 2] = b4.z; rbv[4 * h + 3] = b4.w;
-        }
+        const float4 t4 = *reinterpret_cast<const float4*>(P.a_c1 + n + 4 * h);
+        c1v[4 * h] = t4.x; c1v[4 * h + 1] = t4.y; c1v[4 * h + 2] = t4.z; c1v[4 * h + 3] = t4.w;
+      }
+    }
+  }
+  if constexpr (FUSE == FUSE_RS) {
+#pragma unroll
+    for (int e = 0; e < CW; ++e) { rgv[e] = 1.f; rbv[e] = 0.f; }
+    if (stp && n + CW - 1 < N) {
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        const float4 g4 = *reinterpret_cast<const float4*>(P.r_gamma + n + 4 * h), b4 = *reinterpret_cast<const float4*>(P.r_beta + n + 4 * h);
+        rgv[4 * h] = g4.x; rgv[4 * h + 1] = g4.y; rgv[4 * h + 2] = g4.z; rgv[4 * h + 3] = g4.w;
+        rbv[4 * h] = b4.x; rbv[4 * h + 1] = b4.y; rbv[4 * h + 2] = b4.z; rbv[4 * h + 3] = b4.w;
       }
     }
   }
@@ -505,19 +535,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       if (r < EROWS && m < M) rres[ps] = *reinterpret_cast<const RawRes*>(Rp + (size_t)m * P.ldr + n);
     }
   }
-  // FUSE: the 4 threads of a tile row exchange their partial sums through LDS, in the part of the drained ring behind the
-  // fp32 image (no extra LDS, no extra barrier): written next to the image, read back by every thread for its own rows
-  float2* lnpart = reinterpret_cast<float2*>(smem + BM * BN * 4);        // [2 sets][4 groups][BM]
-  float2 sa = make_float2(0.f, 0.f), sr2 = make_float2(0.f, 0.f);
-  if constexpr (FUSE) {
-    static_assert(EPASS == 1, "fused epilogue: one pass");
-    static_assert(BM * BN * 4 + 2 * 4 * BM * 8 <= NST * TILE_BYTES, "the partial tables must fit the ring behind the image");
+  // FUSE: the TG threads of a tile row exchange their partial sums through LDS.  The tables live BEHIND ring and image
+  // (launch() adds their bytes), so they are written here, before the barrier that frees the ring: [TG][BM] partial sums,
+  // then [BM] (mean, rstd), finished by the first BM threads between the epilogue's two barriers.
+  constexpr int LNOFF = (NST * TILE_BYTES > BM * BN * 4) ? NST * TILE_BYTES : BM * BN * 4;
+  float2* lnpart = reinterpret_cast<float2*>(smem + LNOFF);              // [TG][BM]
+  float2* lnfin = lnpart + TG * BM;                                      // [BM]
+  if constexpr (FUSE != 0) {
     const int sg = tid / BM;
+    float2 sa = make_float2(0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < SP; ++j) {                 // fixed order: the sums do not depend on the schedule
-      if (sg + 4 * j < P.a_np) { sa.x += pa[j].x; sa.y += pa[j].y; }
-      if (sg + 4 * j < P.r_np) { sr2.x += pr[j].x; sr2.y += pr[j].y; }
+      if (sg + TG * j < snp) { sa.x += pl[j].x; sa.y += pl[j].y; }
     }
+    lnpart[sg * BM + (tid % BM)] = sa;
   }
   auto rows_out = [&](auto act_tag, auto ract_tag) {
   constexpr int ACT = decltype(act_tag)::value, RACT = decltype(ract_tag)::value;   // -1: run-time (see apply_act_c)
@@ -525,9 +556,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   for (int ep = 0; ep < EPASS; ++ep) {
     __syncthreads();                                // every wave is done reading the last stage / the previous image
     GEMM_STAMP(5);
-    if constexpr (FUSE) {
-      lnpart[(0 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sa;
-      lnpart[(1 * 4 + tid / BM) * BM + (tid & (BM - 1))] = sr2;
+    if constexpr (FUSE != 0) {
+      static_assert(FUSE == 0 || EPASS == 1, "fused epilogue: one pass");
+      if (tid < BM) {                              // (mean, rstd) of tile row `tid`: over K for the A operand, over N for the residual
+        float2 t0 = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int g4 = 0; g4 < TG; ++g4) { const float2 u0 = lnpart[g4 * BM + tid]; t0.x += u0.x; t0.y += u0.y; }
+        const float inv = 1.0f / (float)(FUSE == FUSE_A ? K : N);
+        const float mu = t0.x * inv;
+        lnfin[tid] = stp ? make_float2(mu, rsqrtf(fmaxf(t0.y * inv - mu * mu, 0.f) + P.ln_eps)) : make_float2(0.f, 1.f);
+      }
     }
     if (EPASS == 1 || (wm * WM) / EROWS == ep) {
 #pragma unroll
@@ -546,14 +584,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       // the image chunks of all passes are read up front (unconditionally: rows clamped into the image), so that the passes'
       // LDS latencies overlap - the early exit below otherwise keeps every pass's read behind the previous pass's branch
       constexpr int NCH = CW / 4;
-      constexpr bool PRE_IMG = !FUSE && NPASS * NCH <= 16 && NWAVES <= 4;
+      constexpr bool PRE_IMG = NPASS * NCH <= 16 && NWAVES <= 4;
       f32x4 img[PRE_IMG ? NPASS : 1][NCH];
+      float2 msv[(PRE_IMG && FUSE != 0) ? NPASS : 1];
       if constexpr (PRE_IMG) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
           const int rr = min(orow0 + ps * RPP, EROWS - 1);
 #pragma unroll
           for (int h = 0; h < NCH; ++h) img[ps][h] = *reinterpret_cast<const f32x4*>(cimg + rr * BN + (((oc * NCH + h) ^ (rr & 7)) << 2));
+          if constexpr (FUSE != 0) msv[ps] = lnfin[rr];
         }
       }
 #pragma unroll
@@ -561,18 +601,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
         const int r = orow0 + ps * RPP;
         const int m = m0 + ep * EROWS + r;
         if (r >= EROWS || m >= M) break;
-        float2 msa = make_float2(0.f, 1.f), msr = make_float2(0.f, 1.f);   // (mean, rstd) of this row: A operand over K, residual over N
-        if constexpr (FUSE) {
-          float2 t0 = make_float2(0.f, 0.f), t1 = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const float2 u0 = lnpart[(0 * 4 + g4) * BM + r], u1 = lnpart[(1 * 4 + g4) * BM + r];
-            t0.x += u0.x; t0.y += u0.y; t1.x += u1.x; t1.y += u1.y;
-          }
-          const float ia = 1.0f / (float)K, ir = 1.0f / (float)N;
-          msa.x = t0.x * ia; msa.y = rsqrtf(fmaxf(t0.y * ia - msa.x * msa.x, 0.f) + P.ln_eps);
-          msr.x = t1.x * ir; msr.y = rsqrtf(fmaxf(t1.y * ir - msr.x * msr.x, 0.f) + P.ln_eps);
-          if (!P.a_stats) msa = make_float2(0.f, 1.f);          // one select per pass; the per-element code below has no branch
+        float2 ms = make_float2(0.f, 1.f);           // (mean, rstd) of this row: A operand over K (FUSE_A), residual over N (FUSE_RS)
+        if constexpr (FUSE != 0) {
+          if constexpr (PRE_IMG) ms = msv[ps];
+          else ms = lnfin[r];
         }
         float v[CW];
 #pragma unroll
@@ -584,7 +616,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = a4[e];
-            if constexpr (FUSE) x = msa.y * (x - msa.x * c1v[4 * h + e]);     // no a_stats: msa = (0, 1), c1v = 0 -> x, exactly
+            if constexpr (FUSE == FUSE_A) x = ms.y * (x - ms.x * c1v[4 * h + e]);     // no a_stats: ms = (0, 1), c1v = 0 -> x, exactly
             v[4 * h + e] = x + bv[4 * h + e];
           }
         }
@@ -627,10 +659,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
               const float4 rr = raw4(raw);
               rv[0] = rr.x; rv[1] = rr.y; rv[2] = rr.z; rv[3] = rr.w;
             }
-            if constexpr (FUSE) {
-              if (P.r_stats) {
+            if constexpr (FUSE == FUSE_RS) {
+              if (stp) {
 #pragma unroll
-                for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - msr.x) * msr.y * rgv[e] + rbv[e];
+                for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - ms.x) * ms.y * rgv[e] + rbv[e];
               }
             }
             if (RACT > 0 || (RACT < 0 && res_act > 0)) {
@@ -641,14 +673,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
               for (int e = 0; e < CW; ++e) v[e] += rv[e];
             }
           }
-          if constexpr (FUSE) {
-            if (P.stats_out) {        // partial (sum, sum of squares) of this row over the tile's BN columns, from the fp32 values
+          if constexpr (FUSE == FUSE_RS) {
+            if (P.stats_out) {        // partial (sum, sum of squares) of this row over each 64-column block, from the fp32 values
+              static_assert(FUSE != FUSE_RS || BN % 64 == 0, "statistics are kept per 64-column block");
+              constexpr int L64 = 64 / CW;          // consecutive lanes that hold one row's 64 columns (8 or 16): DPP, not LDS shuffles
               float s1 = 0.f, s2 = 0.f;
 #pragma unroll
               for (int e = 0; e < CW; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-#pragma unroll
-              for (int o = 1; o < CPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-              if (oc == 0) reinterpret_cast<float2*>(P.stats_out)[(size_t)m * ((N + 63) / 64) + tn] = make_float2(s1, s2);
+              s1 = dpp_group_sum<L64>(s1); s2 = dpp_group_sum<L64>(s2);
+              if ((oc & (L64 - 1)) == 0) reinterpret_cast<float2*>(P.stats_out)[(size_t)(n >> 6) * M + m] = make_float2(s1, s2);
             }
           }
           if constexpr (CW == 8) {
@@ -697,11 +730,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #endif
 }
 
-template <typename T, typename OutT, int BM, int BN, int NST, bool FUSE = false, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
+template <typename T, typename OutT, int BM, int BN, int NST, int FUSE = 0, int WAVES_M = 2, int WAVES_N = 2, int TRANS = 0>
 int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
   constexpr int smem_main = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
-  constexpr int smem = smem_main;
+  // fused epilogue: the partial-sum and (mean, rstd) tables sit behind ring and (whole) image
+  constexpr int smem = FUSE ? (ring > cimg ? ring : cimg) + (64 * WAVES_M * WAVES_N / BM + 1) * BM * 8 : smem_main;
   DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), smem);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), dim3(total_tiles), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");
@@ -784,8 +818,15 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
     minK = a.p[i].K < minK ? a.p[i].K : minK;
   }
-  bool fuse = false;
-  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out || a.p[i].trans;   // 64x64-only kernels
+  // LayerNorm-fusion kinds (FUSE_A: 64x64 and 128x128x2; FUSE_RS: 64x64 and 128x64x4) and transposed operands (64x64 only)
+  bool fuse_a = false, fuse_rs = false, only64 = false;
+  for (int i = 0; i < a.nprob; ++i) {
+    fuse_a = fuse_a || a.p[i].a_stats;
+    fuse_rs = fuse_rs || a.p[i].r_stats || a.p[i].stats_out;
+    only64 = only64 || a.p[i].trans;
+  }
+  only64 = only64 || ((fuse_a || fuse_rs) && !bf16);        // the wide fused tiles are built for bf16
+  const bool fuse = only64 || fuse_a || fuse_rs;             // no 8-wave tile, no tuning overrides
   // Wide launches (every problem N >= 2304 and K <= 1024: packed QKV, FFN-in; 20 per nav-step): 128x128 with a 2-deep ring
   // (64 KiB: two workgroups per CU) from 200 tiles on - r02t A/B in DESIGN.md section 4.0.  DSRG_GEMM_WIDE /
   // DSRG_GEMM_LONGK (K >= 2048) = "BMxBNxNST:mintiles[,...]" override the candidates (tuning aid; first that reaches its
@@ -798,8 +839,8 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     const char* e = nullptr;
     const bool big = !fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000;      // the 8-wave 256x128 tile below
     if (big) e = nullptr;
-    else if (!fuse && maxM > 64 && minN >= 2304 && maxK <= 1024) e = wide_env ? wide_env : (bf16 ? "128x128x2:200" : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
-    else if (!fuse && maxM > 64 && minK >= 2048) e = longk_env ? longk_env : "128x64x4:1";    // FFN-out: 1.136 -> 1.128 ms per c2 step
+    else if (!only64 && !fuse_rs && maxM > 64 && minN >= 2304 && maxK <= 1024) e = (wide_env && !fuse) ? wide_env : (bf16 ? "128x128x2:200" : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
+    else if (!only64 && !fuse_a && maxM > 64 && minK >= 2048) e = (longk_env && !fuse) ? longk_env : (bf16 || !fuse ? "128x64x4:1" : nullptr);    // FFN-out: 1.136 -> 1.128 ms per c2 step
     else if (!fuse && maxM > 64 && maxK <= 1024) { static const char* narrow_env = getenv("DSRG_GEMM_NARROW"); e = narrow_env; }
     while (e && *e) {
       int tbm = 0, tbn = 0, tnst = 0, tmin = 0;
@@ -823,7 +864,17 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
 template <typename T, typename OutT>
 int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
   int bm, bn, nst;
-  const int tiles = plan_tiles(a, bm, bn, nst, sizeof(T) == 2, fbm, fbn, fnst);
+  int tiles = plan_tiles(a, bm, bn, nst, sizeof(T) == 2, fbm, fbn, fnst);
+  {   // the fused epilogue's wide tiles exist for bf16 storage (128x128x2: bf16 output too): anything else runs on 64x64
+    bool fa = false, frs = false;
+    for (int i = 0; i < a.nprob; ++i) { fa = fa || a.p[i].a_stats; frs = frs || a.p[i].r_stats || a.p[i].stats_out; }
+    const bool wide_ok = sizeof(T) == 2 && ((fa && sizeof(OutT) == 2 && bm == 128 && bn == 128 && nst == 2) || (frs && bm == 128 && bn == 64 && nst == 4));
+    if ((fa || frs) && fbm <= 0 && !(bm == 64 && bn == 64 && (nst == 2 || nst == 3)) && !wide_ok) {
+      bm = 64; bn = 64;
+      tiles = count_tiles(a, 64, 64);
+      nst = tiles > 1024 ? 2 : 3;
+    }
+  }
   static const char* gm_env = getenv("DSRG_GEMM_GM");      // tuning aid
   a.gm = gm_env ? atoi(gm_env) : (bm >= 128 ? 1 : 2);      // r02w A/B, c2 step: 4 everywhere 1.0847 ms | 2 everywhere 1.0816 | 1 everywhere 1.0803 | 8: 1.099
   if (a.gm < 1) a.gm = 1;
@@ -845,8 +896,8 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
     }
     a.pw[i] = best_pw;
   }
-  bool fuse = false;
-  for (int i = 0; i < a.nprob; ++i) fuse = fuse || a.p[i].a_stats || a.p[i].r_stats || a.p[i].stats_out;
+  bool fuse_a = false, fuse_rs = false;
+  for (int i = 0; i < a.nprob; ++i) { fuse_a = fuse_a || a.p[i].a_stats; fuse_rs = fuse_rs || a.p[i].r_stats || a.p[i].stats_out; }
   if (a.p[0].trans) {      // backward GEMMs on operands as they lie (no transposed copies); bf16 checked by the entry
     DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
     if constexpr (sizeof(T) == 2) {
@@ -857,10 +908,23 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
     }
     DSRG_CHECK(false, "dsrg_gemm_nt: no kernel for trans=%d", a.p[0].trans);
   }
-  if (fuse) {
-    DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: the LayerNorm-fusion epilogue exists for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
-    if (nst == 2) return launch<T, OutT, 64, 64, 2, true>(a, tiles, s);
-    return launch<T, OutT, 64, 64, 3, true>(a, tiles, s);
+  if (fuse_a || fuse_rs) {
+    DSRG_CHECK(!(fuse_a && fuse_rs), "dsrg_gemm_nt: a_stats and r_stats / stats_out problems cannot share a launch");
+    if (fuse_a) {
+      if (bm == 64 && bn == 64 && nst == 2) return launch<T, OutT, 64, 64, 2, FUSE_A>(a, tiles, s);
+      if (bm == 64 && bn == 64 && nst == 3) return launch<T, OutT, 64, 64, 3, FUSE_A>(a, tiles, s);
+      if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2) {
+        if (bm == 128 && bn == 128 && nst == 2) return launch<T, OutT, 128, 128, 2, FUSE_A>(a, tiles, s);
+      }
+    } else {
+      if (bm == 64 && bn == 64 && nst == 2) return launch<T, OutT, 64, 64, 2, FUSE_RS>(a, tiles, s);
+      if (bm == 64 && bn == 64 && nst == 3) return launch<T, OutT, 64, 64, 3, FUSE_RS>(a, tiles, s);
+      if constexpr (sizeof(T) == 2) {
+        if (bm == 128 && bn == 64 && nst == 4) return launch<T, OutT, 128, 64, 4, FUSE_RS>(a, tiles, s);
+      }
+    }
+    DSRG_CHECK(false, "dsrg_gemm_nt: the LayerNorm-fusion epilogue exists for 64x64 (ring 2 or 3), 128x128x2 (a_stats, bf16 in and out) and "
+               "128x64x4 (r_stats / stats_out, bf16) only, not %dx%dx%d", bm, bn, nst);
   }
 #define DSRG_TILE_CASE(BM_, BN_, NST_) if (bm == BM_ && bn == BN_ && nst == NST_) return launch<T, OutT, BM_, BN_, NST_>(a, tiles, s)
   DSRG_TILE_CASE(64, 64, 2); DSRG_TILE_CASE(64, 64, 3); DSRG_TILE_CASE(64, 64, 4);
@@ -935,6 +999,8 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
                  "dsrg_gemm_nt: problem %d: r_stats needs a residual, r_gamma, r_beta and 1 <= r_np <= 16", i);
       DSRG_CHECK(!p.stats_out || (p.N % 64 == 0 && ((uintptr_t)p.stats_out & 7) == 0), "dsrg_gemm_nt: problem %d: stats_out needs N %% 64 == 0", i);
       DSRG_CHECK(p.ln_eps > 0.f || (!p.a_stats && !p.r_stats), "dsrg_gemm_nt: problem %d: ln_eps must be positive", i);
+      DSRG_CHECK(!(p.a_stats && (p.r_stats || p.stats_out)), "dsrg_gemm_nt: problem %d: a_stats cannot be combined with r_stats / stats_out", i);
+      DSRG_CHECK(p.M > 0 && (size_t)p.M * 16 * 8 < ((size_t)1 << 31), "dsrg_gemm_nt: problem %d: too many rows for the statistics tables", i);
     }
     a.p[live++] = p;
   }

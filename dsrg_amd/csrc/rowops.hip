@@ -497,21 +497,26 @@ __device__ __forceinline__ void ms_combine(float& m, float& s, float om, float o
 __global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ targets,
                                                           int64_t ignore, float* __restrict__ lse_rows, float* __restrict__ loss_rows, int N) {
   __shared__ float sm[4], ss[4];
+  __shared__ int snan[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (size_t)b * ld;
   float m = -INFINITY, s = 0.f;
-  for (int j = tid; j < N; j += 256) {
+  bool bad = false;           // a NaN logit fails both comparisons below: it is carried separately and poisons the row's lse,
+  for (int j = tid; j < N; j += 256) {      // as F.cross_entropy's log_softmax does (a diverged step then shows in the logged loss)
     const float v = row[j];
+    bad = bad || (v != v);
     if (v > m) { s = s * __expf(m - v) + 1.f; m = v; }      // exp(-inf - v) = 0 on the first finite value
     else if (v > -INFINITY) s += __expf(v - m);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ms_combine(m, s, __shfl_xor(m, o), __shfl_xor(s, o));
-  if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+  const bool wbad = __any((int)bad) != 0;
+  if (lane == 0) { sm[wave] = m; ss[wave] = s; snan[wave] = wbad ? 1 : 0; }
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < 4; ++w) ms_combine(m, s, sm[w], ss[w]);     // fixed order
-    const float lse = m + logf(s);
+    const bool anybad = (snan[0] | snan[1] | snan[2] | snan[3]) != 0;
+    const float lse = anybad ? __builtin_nanf("") : m + logf(s);
     const int64_t t = targets[b];
     const bool live = t != ignore && t >= 0 && t < N;
     lse_rows[b] = lse;

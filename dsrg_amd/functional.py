@@ -42,7 +42,9 @@ PACK_EPOCH = [0]
 
 
 def pack_version(srcs):
-    return (PACK_EPOCH[0],) + tuple(p._version for p in srcs)
+    """cache key of a pack: the epoch above, every source's version counter, and every source's storage address (a
+    parameter re-seated with `p.data = ...` / load_state_dict(assign=True) moves neither of the first two)"""
+    return (PACK_EPOCH[0],) + tuple(p._version for p in srcs) + tuple(p.data_ptr() for p in srcs)
 
 
 class _PackFn(torch.autograd.Function):
@@ -58,7 +60,9 @@ class _PackFn(torch.autograd.Function):
             # Everything that does not change from step to step (detached flat aliases of the parameters, the layout of the
             # packed buffers, the grouping by dtype pair) is computed once per packer: a step then costs one allocation and one
             # split per output dtype, the multi-tensor copies, and one view per output - not ~4 tensor ops per parameter.
-            if plan is None:
+            # the plan aliases the parameters' storage: a parameter whose storage was swapped outside Module._apply
+            # (`p.data = ...`, vector_to_parameters, an EMA swap, load_state_dict(assign=True)) invalidates it
+            if plan is None or plan['ptrs'] != [t.data_ptr() for t in srcs]:
                 plan = spec.plan = _pack_plan(spec, srcs)
             flats = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
             parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
@@ -145,7 +149,8 @@ def _pack_plan(spec, srcs):
             g[0].append(len(sz)); g[1].append(srcs[i].detach().view(-1))
             sz.append(n); off += n
         total[dtype] = off
-    return {'dev': dev, 'total': total, 'sizes': sizes, 'copies': copies, 'outs': outs, 'meta': [(t.shape, t.dtype, t.device) for t in srcs]}
+    return {'dev': dev, 'total': total, 'sizes': sizes, 'copies': copies, 'outs': outs, 'meta': [(t.shape, t.dtype, t.device) for t in srcs],
+            'ptrs': [t.data_ptr() for t in srcs]}
 
 
 class WeightPacker:

@@ -108,9 +108,10 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
     Returns list of outputs [.., N] (dtype = x dtype, or fp32 if out_f32).  tile=(bm, bn, nst) pins the block tile
     (dsrg_gemm_nt_tiled; tuning only).
     fuse: optional list (one entry per problem, None = plain) of dicts for the LayerNorm-fusion epilogue of
-    dsrg_gemm_problem_t: 'a_stats': (partials [M, K/64, 2] fp32, c1 [N] fp32) - x holds an un-normalised row and w / bias
-    are the gamma-folded weight and beta-folded bias; 'r_stats': (partials [M, N/64, 2], gamma [N], beta [N]) - the residual
-    is un-normalised; 'stats_out': fp32 [M, N/64, 2] to receive this launch's partials; 'eps'.
+    dsrg_gemm_problem_t: 'a_stats': (partials [K/64, M, 2] fp32, c1 [N] fp32) - x holds an un-normalised row and w / bias
+    are the gamma-folded weight and beta-folded bias; 'r_stats': (partials [N/64, M, 2], gamma [N], beta [N]) - the residual
+    is un-normalised; 'stats_out': fp32 [N/64, M, 2] to receive this launch's partials; 'eps'.  (Block-major tables: one
+    64-column block of all rows is contiguous.)
     trans (dsrg_gemm_problem_t::trans, bf16 only): bit 0 - x is stored [K, M]; bit 1 - w is stored [K, N] (2-D tensors, row
     stride free): the backward GEMMs of a linear layer on dY, W and X as they lie.  colsums (trans bit 0): optional list of
     fp32 [M] tensors (or None) that receive the column sums of the stored x (= the bias gradient with dW = dY^T.X).
@@ -171,20 +172,20 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
             g.ln_eps = float(f.get('eps', 1e-12))
             if f.get('a_stats') is not None:
                 st, c1 = f['a_stats']
-                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, K // 64, 2) or K % 64 or c1.shape != (N,) \
+                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (K // 64, M, 2) or K % 64 or c1.shape != (N,) \
                         or c1.dtype != torch.float32 or not c1.is_contiguous():
-                    raise _lib.DsrgHipError('gemm: a_stats must be contiguous fp32 [M, K/64, 2] with c1 fp32 [N]')
+                    raise _lib.DsrgHipError('gemm: a_stats must be contiguous fp32 [K/64, M, 2] with c1 fp32 [N]')
                 g.a_stats, g.a_c1, g.a_np = _p(st), _p(c1), K // 64
             if f.get('r_stats') is not None:
                 st, ga, be = f['r_stats']
-                if r is None or st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, N // 64, 2) or N % 64 \
+                if r is None or st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (N // 64, M, 2) or N % 64 \
                         or any(t.shape != (N,) or t.dtype != torch.float32 or not t.is_contiguous() for t in (ga, be)):
-                    raise _lib.DsrgHipError('gemm: r_stats must be contiguous fp32 [M, N/64, 2] with gamma, beta fp32 [N] and a residual')
+                    raise _lib.DsrgHipError('gemm: r_stats must be contiguous fp32 [N/64, M, 2] with gamma, beta fp32 [N] and a residual')
                 g.r_stats, g.r_gamma, g.r_beta, g.r_np = _p(st), _p(ga), _p(be), N // 64
             if f.get('stats_out') is not None:
                 st = f['stats_out']
-                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (M, N // 64, 2) or N % 64:
-                    raise _lib.DsrgHipError('gemm: stats_out must be contiguous fp32 [M, N/64, 2]')
+                if st.dtype != torch.float32 or not st.is_contiguous() or st.shape != (N // 64, M, 2) or N % 64:
+                    raise _lib.DsrgHipError('gemm: stats_out must be contiguous fp32 [N/64, M, 2]')
                 g.stats_out = _p(st)
         res.append(out)
     odt = F32 if out_f32 else dt
@@ -192,14 +193,16 @@ def gemm(problems, act=_lib.ACT_NONE, out_f32=False, outs=None, tile=None, fuse=
         _lib.check(lib.dsrg_gemm_nt_tiled(arr, n, dt, odt, act, tile[0], tile[1], tile[2] if len(tile) > 2 else 0, _stream()), 'dsrg_gemm_nt_tiled')
         return res
     _lib.check(lib.dsrg_gemm_nt(arr, n, dt, odt, act, _stream()), 'dsrg_gemm_nt')
-    if want_pre:
-        return res, pres
-    if GEMM_TRACE is not None:
+    if GEMM_TRACE is not None:      # (before the want_pre return: the training-forward FFN-in launches are recorded too)
         bm, bn, nt, nst = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib.dsrg_gemm_nt_plan(arr, n, dt, C.byref(bm), C.byref(bn), C.byref(nt), C.byref(nst))
-        keep = [t for p in problems for t in p if t is not None] + res + [fuse]
-        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value), 'fuse': bool(fuse) and any(f for f in fuse), 'trans': int(arr[0].trans),
+        # everything a replay of this record reads or writes stays alive with it: operands, outputs, pre-activations,
+        # LayerNorm-fusion operands and the column-sum targets (slices of pooled zero chunks)
+        keep = [t for p in problems for t in p if t is not None] + res + pres + [fuse] + [c for c in (colsums or []) if c is not None]
+        GEMM_TRACE.append({'arr': arr, 'n': n, 'dt': dt, 'odt': odt, 'act': act, 'tile': (bm.value, bn.value, nst.value), 'fuse': 0 if not (fuse and any(f for f in fuse)) else (1 if any(f and f.get('a_stats') is not None for f in fuse) else 2), 'trans': int(arr[0].trans),
                            'wgs': nt.value, 'flops': sum(2.0 * a.M * a.N * a.K for a in arr), 'keep': keep})
+    if want_pre:
+        return res, pres
     return res
 
 

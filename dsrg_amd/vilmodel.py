@@ -621,7 +621,7 @@ class GlocalTextPathNavCMT(nn.Module):
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
         dev = feats[0].device
         Ms = [f.shape[0] * f.shape[1] for f in feats]
-        new_stats = lambda: [torch.empty(m, H // 64, 2, device=dev, dtype=torch.float32) for m in Ms]
+        new_stats = lambda: [torch.empty(H // 64, m, 2, device=dev, dtype=torch.float32) for m in Ms]
         # per branch: (tensor, stats | None, LayerNorm key | None): a materialised input, or an un-normalised y
         cur = [(f, None, None) for f in feats]
 

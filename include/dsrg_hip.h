@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 11
+#define DSRG_ABI_VERSION 12
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -49,14 +49,19 @@ typedef struct {
   /* Optional LayerNorm fusion (all NULL / 0 = plain GEMM).  A post-LN block  x1 = LN(y),  y = dense(..) + residual
    * (BertSelfOutput / BertOutput, FT/vilmodel.py:173-177, 213-217) followed by projections of x1 needs no standalone
    * LayerNorm launch and no fp32 copy of y:
-   *  - stats_out: float2 [M, ceil(N/64)]: the launch that produces y also writes, per row and per 64-column tile, the
-   *    partial (sum, sum of squares) of the fp32 values it stores (N % 64 == 0; forces the 64-column tile);
+   *  Partial statistics are float2 (sum, sum of squares) per row and per 64-column block, stored BLOCK-major: table[p * M + m]
+   *  for block p of row m (ABI v12; v11 was row-major): a wave's 64 rows of one block are contiguous.
+   *  - stats_out: float2 [N/64][M]: the launch that produces y also writes the partials of the fp32 values it stores
+   *    (N % 64 == 0);
    *  - a_stats / a_np / a_c1: A holds the UN-normalised y [M,K] of a previous launch and a_stats its partials
    *    (a_np per row, a_np = K/64 <= 16).  With W' = W * diag(gamma) as the weight, a_c1[n] = sum_k W'[n,k] and
    *    bias[n] = b[n] + sum_k beta[k] W[n,k] the epilogue computes  rstd_m * (acc - mu_m * a_c1[n]) + bias[n]
    *    = LN(y) W^T + b  (exact in real arithmetic; mu, rstd over the K columns of A with ln_eps);
    *  - r_stats / r_np / r_gamma / r_beta: the residual holds an un-normalised y' [M,N] and r_stats its partials; the
-   *    residual added is LN(y')[m,n] = (y' - mu'_m) * rstd'_m * r_gamma[n] + r_beta[n]. */
+   *    residual added is LN(y')[m,n] = (y' - mu'_m) * rstd'_m * r_gamma[n] + r_beta[n].
+   *  A problem uses either a_stats or r_stats / stats_out, and all fused problems of one launch are of one kind.  Tiles built
+   *  for the fused epilogue: 64x64 (both dtypes), 128x128 for a_stats (bf16 in and out) and 128x64 for r_stats / stats_out
+   *  (bf16); the plan picks among them. */
   const float* a_stats; const float* a_c1;
   const float* r_stats; const float* r_gamma; const float* r_beta;
   float* stats_out;

@@ -42,7 +42,7 @@ def test_gemm_plan_and_tile_validation_without_gpu():
     """dsrg_gemm_nt_plan is a host-only query and dsrg_gemm_nt_tiled validates its tile before any launch: the nav-step
     N = 768 shapes get the 64x64 tile with a 3-deep ring, the wide ones (packed QKV, FFN-in) 128x128 with a 2-deep ring (bf16;
     fp32: 64x64, 2-deep above 1024 tiles), FFN-out (K >= 2048) 128x64 with a 4-deep ring, the once-per-episode text K/V panel
-    the 8-wave 256x128 tile (bf16 only), a LayerNorm-fusion problem always the 64-column tile, and a tile that is not built is
+    the 8-wave 256x128 tile (bf16 only), a LayerNorm-fusion problem the 64x64 tile or its kind's wide tile (a_stats: 128x128x2, r_stats / stats_out: 128x64x4; bf16), and a tile that is not built is
     EINVAL."""
     import ctypes as C
     from dsrg_amd import _lib
@@ -60,7 +60,11 @@ def test_gemm_plan_and_tile_validation_without_gpu():
     assert plan(2432, 2304, 768) == (128, 128, 2, 19 * 18)
     assert plan(2432, 2304, 768, _lib.F32) == (64, 64, 2, 38 * 36)
     assert plan(2432, 768, 3072) == (128, 64, 4, 19 * 12)
-    assert plan(2432, 2304, 768, a_stats=16)[:2] == (64, 64)
+    assert plan(2432, 2304, 768, a_stats=16)[:3] == (128, 128, 2)       # LayerNorm-fusion consumers keep the wide tile (bf16)
+    assert plan(2432, 768, 768, a_stats=16)[:3] == (64, 64, 3)
+    assert plan(2432, 2304, 768, _lib.F32, a_stats=16)[:2] == (64, 64)
+    assert plan(2432, 768, 3072, stats_out=16, r_stats=16)[:3] == (128, 64, 4)     # ... and the producers theirs
+    assert plan(2432, 768, 768, stats_out=16)[:3] == (64, 64, 3)
     assert plan(5120, 12288, 768) == (256, 128, 3, 20 * 96)
     assert plan(5120, 12288, 768, _lib.F32)[:3] == (128, 128, 2)
     assert plan(5120, 12288, 768, stats_out=16)[:2] == (64, 64)

@@ -181,3 +181,23 @@ def test_bench_gpus_flag_spawns_ranks():
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, RANK='0', WORLD_SIZE='3'),
                        capture_output=True, timeout=300)
     assert p.returncode != 0 and b'WORLD_SIZE=3' in p.stderr
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """A rank that dies mid-run (here: rank 1 right after the first collective, while rank 0 waits in the next one) must not
+    leave the parent blocked: the launcher stops the surviving ranks and returns non-zero within seconds; and an overall
+    time limit bounds a run in which nobody dies but nobody finishes."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(DSRG_BENCH_SPAWN_SELFTEST='1', DSRG_BENCH_SELFTEST_DIE_RANK='1')
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, timeout=240)
+    took = time.monotonic() - t0
+    assert p.returncode != 0
+    assert b'rank 1 exited with code 17' in p.stderr, p.stderr.decode()[-2000:]
+    assert took < 120, took            # dominated by two `import torch`; the surviving rank is not waited for
+    # nobody dies, rank 3 of 2 does not exist: the die hook makes every rank sleep 1 s; with a 0.2 s limit the launcher gives up
+    env.update(DSRG_BENCH_SELFTEST_DIE_RANK='99', DSRG_BENCH_SPAWN_TIMEOUT='0.2')
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, timeout=240)
+    assert p.returncode != 0 and b'no result after' in p.stderr

@@ -153,13 +153,13 @@ def test_gemm_layernorm_fusion(K, dtype, M, H, N2, act):
     w1, b1 = _r(N2, H, seed=6, scale=0.05, dtype=dtype), _r(N2, seed=7)
     w2, b2 = _r(H, N2, seed=8, scale=0.05, dtype=dtype), _r(H, seed=9)
     np_ = H // 64
-    st = torch.zeros(M, np_, 2, device='cuda')
+    st = torch.zeros(np_, M, 2, device='cuda')          # block-major partial tables (ABI v12)
     # launch 1: y (storage dtype) + partials
     y = K.gemm([(x, w0, b0, r)], 0, False, fuse=[{'stats_out': st}])[0]
     y_ref = x.float() @ w0.float().T + b0 + r.float()
     tol = 2e-5 * math.sqrt(H) if dtype == torch.float32 else 3e-2
     assert (y.float() - y_ref).abs().max().item() <= tol * max(1.0, y_ref.abs().max().item())
-    s_ref = torch.stack([y_ref.view(M, np_, 64).sum(-1), (y_ref.view(M, np_, 64) ** 2).sum(-1)], -1)
+    s_ref = torch.stack([y_ref.view(M, np_, 64).sum(-1), (y_ref.view(M, np_, 64) ** 2).sum(-1)], -1).transpose(0, 1)
     assert (st - s_ref).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.3) * max(1.0, s_ref.abs().max().item()) * 1e-2
     # the reference of what follows normalises the y that was STORED (bf16: its rounding is part of the design), with the
     # statistics of the fp32 values
@@ -172,12 +172,12 @@ def test_gemm_layernorm_fusion(K, dtype, M, H, N2, act):
     tol2 = 3e-4 if dtype == torch.float32 else 6e-2
     assert (h.float() - h_ref).abs().max().item() <= tol2 * max(1.0, h_ref.abs().max().item()), (h.float() - h_ref).abs().max().item()
     # launch 3: h W2^T + b2 + LN(y) as the residual, fp32 out, and partials of ITS output
-    st3 = torch.zeros(M, np_, 2, device='cuda')
+    st3 = torch.zeros(np_, M, 2, device='cuda')
     z = K.gemm([(h, w2, b2, y)], 0, True, fuse=[{'r_stats': (st, gamma, beta), 'stats_out': st3, 'eps': eps}])[0]
     z_ref = h.float() @ w2.float().T + b2 + x1
     tol3 = 2e-5 * math.sqrt(N2) if dtype == torch.float32 else 1e-3 * math.sqrt(N2) / 16
     assert (z - z_ref).abs().max().item() <= tol3 * max(1.0, z_ref.abs().max().item()), (z - z_ref).abs().max().item()
-    s3 = torch.stack([z.view(M, np_, 64).sum(-1), (z.view(M, np_, 64) ** 2).sum(-1)], -1)
+    s3 = torch.stack([z.view(M, np_, 64).sum(-1), (z.view(M, np_, 64) ** 2).sum(-1)], -1).transpose(0, 1)
     assert (st3 - s3).abs().max().item() <= 1e-4 * max(1.0, s3.abs().max().item())
     # and both fused features in one grouped launch next to a plain problem
     o = K.gemm([(y, w1f, b1f, None), (x, w0, b0, None)], act, False, fuse=[{'a_stats': (st, c1), 'eps': eps}, None])
@@ -838,6 +838,17 @@ def test_cross_entropy_rows(K, B, N):
         assert torch.equal(Fn.cross_entropy_rows(lg0, tg), got.detach())
     d16 = K.ce_rows_bwd(lg0, tg, K.ce_rows(lg0, tg)[1], gup, out_dtype=torch.bfloat16)
     assert (d16.float() - b.grad).abs().max().item() <= 8e-3
+    # a NaN logit away from the target poisons its row's loss, as in F.cross_entropy (the other rows stay as they were)
+    if N > 4:
+        lgn = lg0.clone()
+        row = 1 if B > 1 else 0
+        col = (int(tg[row].item()) + 2) % N if int(tg[row].item()) >= 0 else 0
+        lgn[row, col] = float('nan')
+        wn = torch.nn.functional.cross_entropy(lgn, tg, reduction='none')
+        gn = Fn.cross_entropy_rows(lgn, tg)
+        assert torch.equal(torch.isnan(gn), torch.isnan(wn))
+        ok = ~torch.isnan(wn)
+        assert (gn[ok] - wn[ok]).abs().max().item() <= 1e-5 * max(1.0, wn[ok].abs().max().item())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

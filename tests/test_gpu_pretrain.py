@@ -210,3 +210,17 @@ def test_forward_sees_the_optimizer_step(make_opt):
     l2 = m2(b, 'sap', compute_loss=True)
     if float(PT_CFG.get('hidden_dropout_prob', 0.0)) == 0.0:
         assert (l1 - l2).abs().max().item() <= 1e-4                # grad-mode pack refreshed as well
+    # a parameter re-seated on new storage (`p.data = ...`: EMA swaps, vector_to_parameters, load_state_dict(assign=True))
+    # moves neither its version counter nor the pack epoch: the pack must follow the storage address
+    with torch.no_grad():
+        for mm in (m, m2):
+            w = mm.bert.global_encoder.encoder.x_layers[0].visn_inter.dense.weight
+            w.data = (w.data * 1.5).clone()
+    l1 = m(b, 'sap', compute_loss=True)
+    m3 = _model(torch.float32)
+    m3.load_state_dict(m.state_dict())
+    m3.train()
+    l3 = m3(b, 'sap', compute_loss=True)
+    if float(PT_CFG.get('hidden_dropout_prob', 0.0)) == 0.0:
+        assert (l1 - l3).abs().max().item() <= 1e-4
+        assert (l1 - l2.detach()).abs().max().item() > 1e-5          # ... and the re-seated weight did change the losses

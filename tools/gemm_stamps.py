@@ -25,10 +25,62 @@ SHAPES = [
 TILES = [None, (64, 64, 3), (128, 128, 2), (128, 128, 3), (256, 128, 2), (256, 128, 3)] if '--tiles' in sys.argv else [None]
 
 
+def fuse_main(lib, fn):
+    """--fuse: the LayerNorm-fusion (FUSE) instantiations next to the plain kernels they replace, local-branch shapes
+    (2432 rows): producer = dense + residual writing bf16 y + partial statistics (r_stats + stats_out) vs the plain fp32-out
+    launch; consumer = projection of LN(y) (a_stats) on the 64x64 FUSE tile vs the plain launch on its planned tile."""
+    dt = torch.bfloat16
+    M, H = 2432, 768
+    dev = 'cuda'
+    rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1)
+    cases = []
+    for name, N, Kd, act in (('co/so N=768 K=768', 768, 768, 0), ('ff2 N=768 K=3072', 768, 3072, 0)):
+        x, w, b, r = rnd(M, Kd).to(dt), (rnd(N, Kd) * 0.05).to(dt), rnd(N), rnd(M, N).to(dt)
+        st_in, st_out = torch.rand(N // 64, M, 2, device=dev), torch.empty(N // 64, M, 2, device=dev)
+        g, be = torch.rand(N, device=dev) + 0.5, rnd(N)
+        cases.append((name + ' plain f32+res', [(x, w, b, r)], act, True, None, None))
+        cases.append((name + ' plain bf16+res', [(x, w, b, r)], act, False, None, None))
+        cases.append((name + ' FUSE stats_out', [(x, w, b, r)], act, False, [{'stats_out': st_out, 'eps': 1e-12}], None))
+        cases.append((name + ' FUSE r_stats+stats_out', [(x, w, b, r)], act, False, [{'r_stats': (st_in, g, be), 'stats_out': st_out, 'eps': 1e-12}], None))
+    for name, N, Kd, act in (('cq N=768 K=768', 768, 768, 0), ('qkv N=2304 K=768', 2304, 768, 0), ('ff1 N=3072 K=768 gelu', 3072, 768, 1)):
+        x, w, b = rnd(M, Kd).to(dt), (rnd(N, Kd) * 0.05).to(dt), rnd(N)
+        st_in, c1 = torch.rand(Kd // 64, M, 2, device=dev), rnd(N)
+        cases.append((name + ' plain (planned tile)', [(x, w, b, None)], act, False, None, None))
+        cases.append((name + ' plain 64x64x3', [(x, w, b, None)], act, False, None, (64, 64, 3)))
+        cases.append((name + ' FUSE a_stats', [(x, w, b, None)], act, False, [{'a_stats': (st_in, c1), 'eps': 1e-12}], None))
+    for name, ps, act, of32, fz, tile in cases:
+        outs = K.gemm(ps, act, of32, fuse=fz, tile=tile)
+        for _ in range(5):
+            K.gemm(ps, act, of32, outs=outs, fuse=fz, tile=tile)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        assert lib.dsrg_debug_gemm_stamps_clear() == 0
+        torch.cuda.synchronize()
+        e0.record(); K.gemm(ps, act, of32, outs=outs, fuse=fz, tile=tile); e1.record(); e1.synchronize()
+        report(name, fn, e0.elapsed_time(e1))
+
+
+def report(name, fn, ms):
+    buf = np.zeros(8192 * 8, np.uint64)
+    assert fn(buf.ctypes.data, buf.nbytes) == 0
+    st = buf.reshape(8192, 8)
+    n = int((st[:, 3] > 0).sum())
+    st = st[:n].astype(np.int64)
+    t00 = st[:, 0].min()
+    span = st[:, 3].max() - t00
+    ph = [st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]]
+    q = lambda a: '%6d %6d %6d' % tuple(np.percentile(a, [10, 50, 90]))
+    print('%-44s wgs %5d  event %.1f us  span %7d clk' % (name, n, ms * 1e3, span))
+    print('    prologue %s | K loop %s | epilogue %s | total %s  (clk, 10/50/90%%)' % (q(ph[0]), q(ph[1]), q(ph[2]), q(st[:, 3] - st[:, 0])))
+    print('    epilogue split: wait-for-waves %s | image write + barrier %s | rows out %s' % (q(st[:, 5] - st[:, 2]), q(st[:, 6] - st[:, 5]), q(st[:, 3] - st[:, 6])))
+
+
 def main():
     lib = _lib.load()
     fn = lib.dsrg_debug_gemm_stamps
     fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    if '--fuse' in sys.argv:
+        return fuse_main(lib, fn)
     dt = torch.bfloat16
     for name in [(n_ + (' tile %dx%dx%d' % t_ if t_ else ''), p_, a_, o_, r_, t_) for (n_, p_, a_, o_, r_) in SHAPES for t_ in TILES]:
         name, probs, act, of32, res, tile = name
