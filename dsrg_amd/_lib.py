@@ -40,7 +40,8 @@ class AttnProblem(C.Structure):
     _fields_ = [('Q', C.c_void_p), ('K', C.c_void_p), ('V', C.c_void_p), ('O', C.c_void_p),
                 ('q_bs', C.c_int64), ('k_bs', C.c_int64), ('v_bs', C.c_int64), ('o_bs', C.c_int64),
                 ('q_rs', C.c_int32), ('k_rs', C.c_int32), ('v_rs', C.c_int32), ('o_rs', C.c_int32),
-                ('kmask', C.c_void_p), ('pair_dists', C.c_void_p), ('lse', C.c_void_p), ('Nq', C.c_int32), ('Nk', C.c_int32)]
+                ('kmask', C.c_void_p), ('pair_dists', C.c_void_p), ('lse', C.c_void_p), ('Nq', C.c_int32), ('Nk', C.c_int32),
+                ('klens', C.c_void_p), ('kseg', C.c_int32), ('klens2', C.c_void_p)]
 
 
 ATTN_MAX_GROUPS = 4
@@ -68,7 +69,9 @@ class GraphNavOut(C.Structure):
 
 class LnProblem(C.Structure):
     _fields_ = [('x', C.c_void_p), ('residual', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('out', C.c_void_p),
-                ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32)]
+                ('M', C.c_int32), ('ldx', C.c_int32), ('ldr', C.c_int32), ('ldo', C.c_int32),
+                ('o_seg', C.c_int32), ('o_seg_ld', C.c_int32), ('aux0', C.c_void_p), ('aux1', C.c_void_p),
+                ('aux_seg', C.c_int32), ('aux_ld0', C.c_int32), ('aux_ld1', C.c_int32), ('reserved_', C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -93,10 +96,14 @@ SIGNATURES = {
     'dsrg_layernorm_bwd_drop': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _F, C.c_uint64, _I, _P]),
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
                                     _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
+    'dsrg_embed_ln_fwd_seg': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
+                                        _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'dsrg_gaa_pool_fwd_ex': (C.c_int, [_P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_nav_logits_fwd_og': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_transpose_pad': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'dsrg_head_tail_fwd_grouped': (C.c_int, [C.POINTER(HeadTailProblem), _I, _I, C.c_float, _P]),
     'dsrg_transpose_pad_grouped': (C.c_int, [C.POINTER(TransposeProblem), _I, _P]),

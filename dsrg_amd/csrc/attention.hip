@@ -23,7 +23,19 @@ struct AttnArgs {
   int NH;
   float p_drop;               // attention-probability dropout (training); 0 = off
   unsigned long long seed;
+  // key validity from lengths instead of a bool mask (forward kernels): key k is valid iff k % kseg < klens[b, k / kseg]
+  // (dsrg_attn_problem_t::klens: no mask-building kernel in front of the attention launch)
+  const int64_t* klens; int kseg;
+  const int64_t* klens2;      // optional second lengths tensor, added to the first (REVERIE: view_lens + obj_lens)
 };
+// valid[b, key] from the bool mask or from the lengths
+__device__ __forceinline__ bool key_valid(const AttnArgs& a, int b, int key) {
+  if (a.klens) {
+    const int sg = key / a.kseg, nseg = (a.Nk + a.kseg - 1) / a.kseg;
+    return key - sg * a.kseg < (int)a.klens[(size_t)b * nseg + sg] + (a.klens2 ? (int)a.klens2[(size_t)b * nseg + sg] : 0);
+  }
+  return a.kmask[(size_t)b * a.Nk + key] != 0;
+}
 
 // Dropout on the attention probabilities (vilmodel.py:115,150; nn.MultiheadAttention(dropout=)): drop_keep() of common.h on
 // the flat index of element (b, h, q, k); the backward recomputes the same mask and no mask tensor exists.
@@ -43,7 +55,7 @@ struct AttnGroup {
   asm volatile("" ::"s"(a_.Q), "s"(a_.K), "s"(a_.V), "s"(a_.O), "s"(a_.q_bs), "s"(a_.k_bs), "s"(a_.v_bs), "s"(a_.o_bs),         \
                "s"(a_.q_rs), "s"(a_.k_rs), "s"(a_.v_rs), "s"(a_.o_rs), "s"(a_.kmask), "s"(a_.mask_mode), "s"(a_.dists),          \
                "s"(a_.sprel_w), "s"(a_.sprel_b), "s"(a_.Nq), "s"(a_.Nk), "s"(a_.scale), "s"(a_.lse), "s"(a_.NH), "s"(a_.p_drop), \
-               "s"(a_.seed))
+               "s"(a_.seed), "s"(a_.klens), "s"(a_.kseg), "s"(a_.klens2))
 #define ATTN_PICK_PROBLEM(grp)                                   \
   AttnArgs a = grp.a[0];                                         \
   ATTN_PIN_PROBLEM(a);                                           \
@@ -101,8 +113,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
     const int key = k0 + lane;
     float mterm = 0.f;
     bool dead = key >= a.Nk;
-    if (!dead && a.kmask) {
-      const bool mk = a.kmask[(size_t)b * a.Nk + key] != 0;
+    if (!dead && (a.kmask || a.klens)) {
+      const bool mk = key_valid(a, b, key);
       if (a.mask_mode == DSRG_MASK_NEG10000) mterm = mk ? 0.f : -10000.0f;
       else if (a.mask_mode == DSRG_MASK_NEGINF) dead = !mk;
       else if (a.mask_mode == DSRG_MASK_PLUS1) mterm = mk ? 1.0f : 0.f;
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
       for (int p = 0; p < 4; ++p)
         vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + min(key, nk - 1)) * a.v_rs + (dc0 + 2 * p) * 8);
       uint8_t mkb = 1;
-      if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + k0 + min(tid & (KC - 1), nk - 1)];
+      if (a.kmask || a.klens) mkb = key_valid(a, b, k0 + min(tid & (KC - 1), nk - 1)) ? 1 : 0;
       float dreg[SPREL ? 32 : 1];
       if constexpr (SPREL) {
         if (use_sp) {          // wave w stages rows 16w .. 16w+15 of the block: two 256-byte pieces per row
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
         float t = -INFINITY;
         if (tid < nk) {
           t = 0.f;
-          if (a.kmask) {
+          if (a.kmask || a.klens) {
             const bool mk = mkb != 0;
             if (a.mask_mode == DSRG_MASK_NEG10000) t = mk ? 0.f : -10000.0f;
             else if (a.mask_mode == DSRG_MASK_NEGINF) t = mk ? 0.f : -INFINITY;
@@ -1014,7 +1026,9 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
     DSRG_CHECK(p.Nq >= 0 && p.Nk >= 1, "dsrg_attention_fwd: problem %d has bad dims Nq=%d Nk=%d", i, p.Nq, p.Nk);
     if (p.Nq == 0) continue;
     DSRG_CHECK(p.Q && p.K && p.V && p.O, "dsrg_attention_fwd: problem %d has a null Q/K/V/O", i);
-    DSRG_CHECK(mask_mode == DSRG_MASK_NONE || p.kmask, "dsrg_attention_fwd: mask_mode %d needs kmask (problem %d)", mask_mode, i);
+    DSRG_CHECK(mask_mode == DSRG_MASK_NONE || p.kmask || p.klens, "dsrg_attention_fwd: mask_mode %d needs kmask or klens (problem %d)", mask_mode, i);
+    DSRG_CHECK(!p.klens || (p.kseg >= 1 && !p.kmask), "dsrg_attention_fwd: problem %d: klens needs kseg >= 1 and no kmask", i);
+    DSRG_CHECK(!p.klens2 || p.klens, "dsrg_attention_fwd: problem %d: klens2 without klens", i);
     DSRG_CHECK(!p.pair_dists || (sprel_w && sprel_b), "dsrg_attention_fwd: pair_dists needs sprel_w and sprel_b");
     DSRG_CHECK(p.q_rs % 4 == 0 && p.k_rs % 4 == 0 && p.v_rs % 4 == 0 && p.q_bs % 4 == 0 && p.k_bs % 4 == 0 && p.v_bs % 4 == 0,
                "dsrg_attention_fwd: problem %d strides must be multiples of 4 elements", i);
@@ -1025,7 +1039,8 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
               p.o_rs % 4 == 0 && p.o_bs % 4 == 0 && (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) == 0 && ((uintptr_t)p.O & 7) == 0;
     grp.a[grp.n++] = AttnArgs{p.Q, p.K, p.V, p.O, p.q_bs, p.k_bs, p.v_bs, p.o_bs, p.q_rs, p.k_rs, p.v_rs, p.o_rs,
                               mask_mode == DSRG_MASK_NONE ? nullptr : p.kmask, mask_mode, p.pair_dists, sprel_w, sprel_b, p.Nq, p.Nk, scale,
-                              p.lse, NH, p_drop, seed + 0x632BE59BD9B4E019ull * (unsigned long long)i};
+                              p.lse, NH, p_drop, seed + 0x632BE59BD9B4E019ull * (unsigned long long)i,
+                              mask_mode == DSRG_MASK_NONE ? nullptr : p.klens, p.kseg, mask_mode == DSRG_MASK_NONE ? nullptr : p.klens2};
   }
   if (B == 0 || grp.n == 0) return DSRG_OK;
   const int qpb = mfma_ok ? 64 : QPB;           // query rows per workgroup
@@ -1063,7 +1078,7 @@ extern "C" int dsrg_attention_fwd(const void* Q, int64_t q_bs, int q_rs, const v
                                   const float* sprel_w, const float* sprel_b,
                                   int B, int NH, int Nq, int Nk, float scale, float* lse, float p_drop, uint64_t seed, int dtype,
                                   void* stream) {
-  const dsrg_attn_problem_t p{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, kmask, pair_dists, lse, Nq, Nk};
+  const dsrg_attn_problem_t p{Q, K, V, O, q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, kmask, pair_dists, lse, Nq, Nk, nullptr, 0, nullptr};
   return dsrg_attention_fwd_grouped(&p, 1, mask_mode, sprel_w, sprel_b, B, NH, scale, p_drop, seed, dtype, stream);
 }
 

@@ -536,19 +536,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     }
   }
   // FUSE: the TG threads of a tile row exchange their partial sums through LDS.  The tables live BEHIND ring and image
-  // (launch() adds their bytes), so they are written here, before the barrier that frees the ring: [TG][BM] partial sums,
+  // (launch() adds their bytes), so they are written here, before the barrier that frees the ring: [4][BM] partial sums,
   // then [BM] (mean, rstd), finished by the first BM threads between the epilogue's two barriers.
   constexpr int LNOFF = (NST * TILE_BYTES > BM * BN * 4) ? NST * TILE_BYTES : BM * BN * 4;
-  float2* lnpart = reinterpret_cast<float2*>(smem + LNOFF);              // [TG][BM]
-  float2* lnfin = lnpart + TG * BM;                                      // [BM]
+  // The summation order is the same for every tile shape (results do not depend on the plan): partial p belongs to group
+  // p % 4, a group is summed in increasing p, the four group sums are added in order 0..3.
+  constexpr int NG = 4;
+  float2* lnpart = reinterpret_cast<float2*>(smem + LNOFF);              // [NG][BM]
+  float2* lnfin = lnpart + NG * BM;                                      // [BM]
   if constexpr (FUSE != 0) {
+    static_assert(NG % TG == 0, "a thread owns NG / TG groups");
+    constexpr int GPT = NG / TG;                   // groups per thread (1 at BM = 64, 2 at BM = 128)
     const int sg = tid / BM;
-    float2 sa = make_float2(0.f, 0.f);
+    float2 sa[GPT];
 #pragma unroll
-    for (int j = 0; j < SP; ++j) {                 // fixed order: the sums do not depend on the schedule
-      if (sg + TG * j < snp) { sa.x += pl[j].x; sa.y += pl[j].y; }
+    for (int gi = 0; gi < GPT; ++gi) sa[gi] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {                 // partial sg + TG*j: group (sg + TG*j) % NG = sg + TG*(j % GPT)
+      if (sg + TG * j < snp) { sa[j % GPT].x += pl[j].x; sa[j % GPT].y += pl[j].y; }
     }
-    lnpart[sg * BM + (tid % BM)] = sa;
+#pragma unroll
+    for (int gi = 0; gi < GPT; ++gi) lnpart[(sg + TG * gi) * BM + (tid % BM)] = sa[gi];
   }
   auto rows_out = [&](auto act_tag, auto ract_tag) {
   constexpr int ACT = decltype(act_tag)::value, RACT = decltype(ract_tag)::value;   // -1: run-time (see apply_act_c)
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       if (tid < BM) {                              // (mean, rstd) of tile row `tid`: over K for the A operand, over N for the residual
         float2 t0 = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int g4 = 0; g4 < TG; ++g4) { const float2 u0 = lnpart[g4 * BM + tid]; t0.x += u0.x; t0.y += u0.y; }
+        for (int g4 = 0; g4 < NG; ++g4) { const float2 u0 = lnpart[g4 * BM + tid]; t0.x += u0.x; t0.y += u0.y; }
         const float inv = 1.0f / (float)(FUSE == FUSE_A ? K : N);
         const float mu = t0.x * inv;
         lnfin[tid] = stp ? make_float2(mu, rsqrtf(fmaxf(t0.y * inv - mu * mu, 0.f) + P.ln_eps)) : make_float2(0.f, 1.f);
@@ -735,7 +743,7 @@ int launch(const GemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int ring = NST * (BM + BN) * ROWB, cimg = BM * BN * 4;
   constexpr int smem_main = ring > cimg ? ring : (ring > cimg / 2 ? ring : cimg / 2);   // an image larger than the ring leaves in two passes
   // fused epilogue: the partial-sum and (mean, rstd) tables sit behind ring and (whole) image
-  constexpr int smem = FUSE ? (ring > cimg ? ring : cimg) + (64 * WAVES_M * WAVES_N / BM + 1) * BM * 8 : smem_main;
+  constexpr int smem = FUSE ? (ring > cimg ? ring : cimg) + (4 + 1) * BM * 8 : smem_main;
   DSRG_SET_MAX_LDS_ONCE((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), smem);
   hipLaunchKernelGGL((gemm_nt_kernel<T, OutT, BM, BN, NST, FUSE, WAVES_M, WAVES_N, TRANS>), dim3(total_tiles), dim3(64 * WAVES_M * WAVES_N), smem, s, a);
   DSRG_LAUNCH_CHECK("dsrg_gemm_nt");

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   // INT_MAX past the last problem) - see gemm.hip: the compiler otherwise chains three dependent load -> wait round trips
   dsrg_ln_problem_t P = a.p[0];
   asm volatile("" ::"s"(P.x), "s"(P.residual), "s"(P.gamma), "s"(P.beta), "s"(P.out), "s"(P.M), "s"(P.ldx), "s"(P.ldr), "s"(P.ldo), "s"(a.H), "s"(a.eps));
+  asm volatile("" ::"s"(P.o_seg), "s"(P.o_seg_ld), "s"(P.aux0), "s"(P.aux1), "s"(P.aux_seg), "s"(P.aux_ld0), "s"(P.aux_ld1));
   int g = 0, bstart = 0;
 #pragma unroll
   for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
@@ -75,9 +76,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   if (g != 0) {
     P = a.p[g];
     asm volatile("" ::"s"(P.x), "s"(P.residual), "s"(P.gamma), "s"(P.beta), "s"(P.out), "s"(P.M), "s"(P.ldx), "s"(P.ldr), "s"(P.ldo));
+    asm volatile("" ::"s"(P.o_seg), "s"(P.o_seg_ld), "s"(P.aux0), "s"(P.aux1), "s"(P.aux_seg), "s"(P.aux_ld0), "s"(P.aux_ld1));
   }
   const int row = ((int)blockIdx.x - bstart) * WPB + (threadIdx.x >> 6);
   if (row >= P.M) return;
+  // output placement (dsrg_ln_problem_t): segmented rows, and a second / third copy of every aux_seg-th row
+  size_t ooff = (size_t)row * P.ldo;
+  if (P.o_seg > 0) { const int sg = row / P.o_seg; ooff = (size_t)sg * P.o_seg_ld + (size_t)(row - sg * P.o_seg) * P.ldo; }
+  TO* __restrict__ ax0 = nullptr;
+  TO* __restrict__ ax1 = nullptr;
+  if (P.aux_seg > 0) {
+    const int ai = row / P.aux_seg;
+    if (row - ai * P.aux_seg == 0) {
+      if (P.aux0) ax0 = reinterpret_cast<TO*>(P.aux0) + (size_t)ai * P.aux_ld0;
+      if (P.aux1) ax1 = reinterpret_cast<TO*>(P.aux1) + (size_t)ai * P.aux_ld1;
+    }
+  }
   const TI* __restrict__ x = reinterpret_cast<const TI*>(P.x) + (size_t)row * P.ldx;
   const TO* __restrict__ res = reinterpret_cast<const TO*>(P.residual);
   TO* __restrict__ out = reinterpret_cast<TO*>(P.out);
@@ -124,9 +138,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < H)
-      st4(out + (size_t)row * P.ldo + c, make_float4((v[i].x - mean) * rstd * gm[i].x + bt[i].x, (v[i].y - mean) * rstd * gm[i].y + bt[i].y,
-                                                     (v[i].z - mean) * rstd * gm[i].z + bt[i].z, (v[i].w - mean) * rstd * gm[i].w + bt[i].w));
+    if (c < H) {
+      const float4 o4 = make_float4((v[i].x - mean) * rstd * gm[i].x + bt[i].x, (v[i].y - mean) * rstd * gm[i].y + bt[i].y,
+                                    (v[i].z - mean) * rstd * gm[i].z + bt[i].z, (v[i].w - mean) * rstd * gm[i].w + bt[i].w);
+      st4(out + ooff + c, o4);
+      if (ax0) st4(ax0 + c, o4);
+      if (ax1) st4(ax1 + c, o4);
+    }
   }
 }
 
@@ -138,6 +156,8 @@ struct EmbedArgs {
   const float* E1; EmbedIdx i1; const float* E2; EmbedIdx i2;
   const float* vec; const float* lno_g; const float* lno_b;
   float eps; void* out; int ldo; int M; int H;
+  // base row gathered from two tables by per-episode lengths (dsrg_embed_ln_fwd_seg); seg_T = 0: base row = row
+  const void* base2; int ldb2; int seg_T, seg_V, seg_No; const int64_t* lens0; const int64_t* lens1;
 };
 
 __device__ __forceinline__ int embed_index(const EmbedIdx& ix, int row) {
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
                "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
                "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
+  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H, nv = (H + 255) / 256, HS = H + 4;
   const int row = blockIdx.x * EWAVES + wave;
@@ -171,6 +192,14 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   // made the compiler wait for it before issuing the next: ~12 memory latencies in a row in the first version's ISA).
   const int rowc = min(row, a.M - 1);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const T* brow = base ? base + (size_t)rowc * a.ldb : nullptr;
+  if (a.seg_T > 0) {         // (uniform per wave) token t of episode b: a view row, an object row, or zero padding
+    const int eb = rowc / a.seg_T, t = rowc - eb * a.seg_T;
+    const int l0 = (int)a.lens0[eb], l1 = (int)a.lens1[eb];
+    if (t < l0) brow = base + ((size_t)eb * a.seg_V + t) * a.ldb;
+    else if (t < l0 + l1) brow = reinterpret_cast<const T*>(a.base2) + ((size_t)eb * a.seg_No + (t - l0)) * a.ldb2;
+    else brow = nullptr;
+  }
   // the row's features: ONE load (lane k holds feature k), broadcast below - F conditional loads were F latencies in a row
   const float fl = a.feat ? a.feat[(size_t)rowc * a.ldf + min(lane, a.F - 1)] : 0.f;
   const int i1 = a.E1 ? embed_index(a.i1, rowc) : 0, i2 = a.E2 ? embed_index(a.i2, rowc) : 0;
@@ -179,7 +208,7 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
   for (int i = 0; i < MAXV; ++i) {
     if (i < nv) {                                   // uniform
       const int cc = min((i * 64 + lane) * 4, H - 4);
-      lb[i] = base ? ld4(base + (size_t)rowc * a.ldb + cc) : z4;
+      lb[i] = brow ? ld4(brow + cc) : z4;
       l1[i] = a.E1 ? *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + cc) : z4;
       l2[i] = a.E2 ? *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + cc) : z4;
       lv[i] = a.vec ? *reinterpret_cast<const float4*>(a.vec + cc) : z4;
@@ -247,13 +276,14 @@ __global__ __launch_bounds__(256) void group_mean_kernel(const T* __restrict__ x
 // forms the weighted sum of ITS OWN rows from registers; the 16 partial sums are combined through LDS.
 constexpr int GWAVES = 16, GVPW = 4;      // V <= 64
 template <typename T>
-__global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                        T* __restrict__ out, int V, int H) {
+__global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x, long x_bs, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ out, T* __restrict__ out2, long out2_bs, const int64_t* __restrict__ idx2,
+                                                        int idx2_max, int V, int H) {
   __shared__ float sc[64];
   extern __shared__ __attribute__((aligned(16))) float part[];     // [GWAVES][H]
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (H + 255) / 256;
-  const T* xb = x + (size_t)b * V * H;
+  const T* xb = x + (size_t)b * x_bs;
   // every load of the wave goes out first, unconditionally (view / column clamped), and is masked afterwards: a
   // `cond ? load : 0` consumes each load at once and the compiler then waits for it before issuing the next
   // (16 memory latencies in a row in the ISA of the first version)
@@ -317,6 +347,7 @@ __global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int g = 0; g < GWAVES; ++g) sum = f4add(sum, *reinterpret_cast<const float4*>(&part[g * H + c]));
     st4(out + (size_t)b * H + c, sum);
+    if (out2) st4(out2 + (size_t)b * out2_bs + (size_t)min(max((int)idx2[b], 0), idx2_max - 1) * H + c, sum);   // (index clamped: never outside the batch's rows)     // the current node's slot of the graph-map token buffer
   }
 }
 
@@ -386,10 +417,14 @@ __global__ __launch_bounds__(64) void nav_logits_kernel(const float* __restrict_
                                                         const uint8_t* __restrict__ gvis, const uint8_t* __restrict__ vnav,
                                                         const int32_t* __restrict__ gsrc, const uint8_t* __restrict__ bwm,
                                                         float* __restrict__ gl, float* __restrict__ ll, float* __restrict__ fl,
-                                                        int G, int Vp) {
+                                                        const float* __restrict__ o_raw, const uint8_t* __restrict__ vobj,
+                                                        float* __restrict__ ol, int G, int Vp) {
   __shared__ float sl[NAV_MAX_VP];
   __shared__ uint8_t sb[NAV_MAX_VP];
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (ol) {          // REVERIE object grounding: masked_fill(~vp_obj_masks, -inf)
+    for (int k = lane; k < Vp; k += 64) ol[(size_t)b * Vp + k] = vobj[(size_t)b * Vp + k] ? o_raw[(size_t)b * Vp + k] : -INFINITY;
+  }
   const float fw = fuse_raw ? 1.0f / (1.0f + expf(-fuse_raw[b])) : 0.5f;
   for (int k = lane; k < Vp; k += 64) {
     float v = l_raw[(size_t)b * Vp + k] * (1.0f - fw);
@@ -599,6 +634,11 @@ static int layernorm_fwd_impl(const dsrg_ln_problem_t* problems, int nproblems, 
     DSRG_CHECK(al16(p.gamma) && al16(p.beta) && ((uintptr_t)p.x & 7) == 0 && ((uintptr_t)p.out & 7) == 0 && ((uintptr_t)p.residual & 7) == 0 &&
                    (in_dtype == DSRG_BF16 || al16(p.x)) && (out_dtype == DSRG_BF16 || (al16(p.out) && al16(p.residual))),
                "dsrg_layernorm_fwd: problem %d has a misaligned pointer", i);
+    DSRG_CHECK(p.o_seg >= 0 && (p.o_seg == 0 || (p.o_seg_ld % 4 == 0 && (size_t)p.o_seg_ld >= (size_t)(p.o_seg - 1) * p.ldo + H)),
+               "dsrg_layernorm_fwd: problem %d: o_seg_ld must be a multiple of 4 and cover a segment of o_seg rows", i);
+    DSRG_CHECK(p.aux_seg >= 0 && (p.aux_seg == 0 || ((!p.aux0 || (p.aux_ld0 % 4 == 0 && p.aux_ld0 >= H && ((uintptr_t)p.aux0 & (out_dtype == DSRG_BF16 ? 7 : 15)) == 0)) &&
+                                                      (!p.aux1 || (p.aux_ld1 % 4 == 0 && p.aux_ld1 >= H && ((uintptr_t)p.aux1 & (out_dtype == DSRG_BF16 ? 7 : 15)) == 0)))),
+               "dsrg_layernorm_fwd: problem %d: aux destinations need leading dims >= H, multiples of 4, and aligned pointers", i);
     a.blk_start[a.nprob] = blocks;
     a.tag[a.nprob] = i;
     a.p[a.nprob++] = p;
@@ -642,7 +682,9 @@ extern "C" int dsrg_layernorm_fwd_grouped_drop(const dsrg_ln_problem_t* problems
 
 extern "C" int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta,
                                   void* out, int ldo, int M, int H, float eps, int in_dtype, int out_dtype, void* stream) {
-  const dsrg_ln_problem_t p{x, residual, gamma, beta, out, M, ldx, ldr, ldo};
+  dsrg_ln_problem_t p{};
+  p.x = x; p.residual = residual; p.gamma = gamma; p.beta = beta; p.out = out;
+  p.M = M; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
   return dsrg_layernorm_fwd_grouped(&p, 1, H, eps, in_dtype, out_dtype, stream);
 }
 
@@ -652,6 +694,22 @@ extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, i
                                  const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
                                  const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
                                  void* out, int ldo, int M, int H, int dtype, void* stream) {
+  return dsrg_embed_ln_fwd_seg(base, ldb, nullptr, 0, 0, 0, 0, nullptr, nullptr, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, idx1, idx1_kind,
+                               idx1_stride, idx1_div, E2, idx2, idx2_kind, idx2_stride, idx2_div, vec, lno_gamma, lno_beta, eps, out, ldo, M, H,
+                               dtype, stream);
+}
+
+extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
+                                     const int64_t* lens0, const int64_t* lens1,
+                                     const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                                     const float* lnf_gamma, const float* lnf_beta,
+                                     const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                                     const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                                     const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                                     void* out, int ldo, int M, int H, int dtype, void* stream) {
+  DSRG_CHECK(seg_T >= 0 && (seg_T == 0 || (base && base2 && lens0 && lens1 && seg_V >= 1 && seg_No >= 1 && M % seg_T == 0 && ldb2 % 4 == 0 &&
+                                           ldb2 >= H && ((uintptr_t)base2 & 7) == 0)),
+             "dsrg_embed_ln_fwd_seg: the gathered base needs both tables, both length vectors, M %% seg_T == 0 and an aligned base2");
   DSRG_CHECK(ok_dtype(dtype), "dsrg_embed_ln_fwd: bad dtype %d", dtype);
   DSRG_CHECK(out && M >= 0, "dsrg_embed_ln_fwd: null out");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_embed_ln_fwd: H=%d must be a multiple of 64 and <= 1024", H);
@@ -666,7 +724,8 @@ extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, i
                  al16(lnf_gamma) && al16(lnf_beta) && al16(bf), "dsrg_embed_ln_fwd: misaligned pointer");
   if (M == 0) return DSRG_OK;
   EmbedArgs a{base, ldb, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, {idx1, idx1_kind, idx1_stride, idx1_div},
-              E2, {idx2, idx2_kind, idx2_stride, idx2_div}, vec, lno_gamma, lno_beta, eps, out, ldo, M, H};
+              E2, {idx2, idx2_kind, idx2_stride, idx2_div}, vec, lno_gamma, lno_beta, eps, out, ldo, M, H,
+              base2, ldb2, seg_T, seg_V, seg_No, lens0, lens1};
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + EWAVES - 1) / EWAVES), block(64 * EWAVES);
   const size_t lds = feat ? (size_t)F * (H + 4) * sizeof(float) : 0;     // <= 16 * 1028 * 4 = 65,792 B
@@ -692,15 +751,23 @@ extern "C" int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, i
 }
 
 extern "C" int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* out, int B, int V, int H, int dtype, void* stream) {
+  return dsrg_gaa_pool_fwd_ex(x, (int64_t)V * H, w, bias, out, nullptr, 0, nullptr, 0, B, V, H, dtype, stream);
+}
+
+extern "C" int dsrg_gaa_pool_fwd_ex(const void* x, int64_t x_bs, const float* w, const float* bias, void* out, void* out2, int64_t out2_bs,
+                                    const int64_t* idx2, int idx2_max, int B, int V, int H, int dtype, void* stream) {
   DSRG_CHECK(ok_dtype(dtype) && x && w && bias && out, "dsrg_gaa_pool_fwd: bad dtype or null pointer");
   DSRG_CHECK(V >= 1 && V <= 64 && H > 0 && H % 4 == 0 && H <= 1024, "dsrg_gaa_pool_fwd: need 1 <= V <= 64 (got %d), H %% 4 == 0 and H <= 1024", V);
   DSRG_CHECK(al16(x) && al16(out) && al16(w), "dsrg_gaa_pool_fwd: misaligned pointer");
+  DSRG_CHECK(x_bs >= (int64_t)V * H && x_bs % 8 == 0, "dsrg_gaa_pool_fwd_ex: x_bs must cover V rows and keep 16-byte alignment");
+  DSRG_CHECK(!out2 || (idx2 && idx2_max >= 1 && out2_bs >= (int64_t)idx2_max * H && out2_bs % 8 == 0 && al16(out2)),
+             "dsrg_gaa_pool_fwd_ex: out2 needs idx2, idx2_max >= 1 and a batch stride that covers idx2_max rows");
   if (B <= 0) return DSRG_OK;
   hipStream_t s = (hipStream_t)stream;
   DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<float>, 65536);     // 16 x 1024 floats + the score vector is just over the 64 KiB default
   DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<bf16_t>, 65536);
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, w, bias, (float*)out, V, H);
-  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, w, bias, (bf16_t*)out, V, H);
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, (long)x_bs, w, bias, (float*)out, (float*)out2, (long)out2_bs, idx2, idx2_max, V, H);
+  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, (long)x_bs, w, bias, (bf16_t*)out, (bf16_t*)out2, (long)out2_bs, idx2, idx2_max, V, H);
   DSRG_LAUNCH_CHECK("dsrg_gaa_pool_fwd");
   return DSRG_OK;
 }
@@ -745,12 +812,21 @@ extern "C" int dsrg_nav_logits_fwd(const float* g_raw, const float* l_raw, const
                                    const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const int32_t* gmap_src,
                                    const uint8_t* bw_mask, float* global_logits, float* local_logits, float* fused_logits,
                                    int B, int G, int Vp, void* stream) {
+  return dsrg_nav_logits_fwd_og(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask, global_logits, local_logits,
+                                fused_logits, nullptr, nullptr, nullptr, B, G, Vp, stream);
+}
+
+extern "C" int dsrg_nav_logits_fwd_og(const float* g_raw, const float* l_raw, const float* fuse_raw, const uint8_t* gmap_masks,
+                                      const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const int32_t* gmap_src,
+                                      const uint8_t* bw_mask, float* global_logits, float* local_logits, float* fused_logits,
+                                      const float* o_raw, const uint8_t* vp_obj_masks, float* obj_logits, int B, int G, int Vp, void* stream) {
   DSRG_CHECK(g_raw && l_raw && gmap_masks && gmap_visited && vp_nav_masks && gmap_src && bw_mask && global_logits && local_logits && fused_logits,
              "dsrg_nav_logits_fwd: null pointer");
+  DSRG_CHECK((o_raw && vp_obj_masks && obj_logits) || (!o_raw && !vp_obj_masks && !obj_logits), "dsrg_nav_logits_fwd_og: o_raw, vp_obj_masks and obj_logits come together");
   DSRG_CHECK(G >= 1 && Vp >= 1 && Vp <= NAV_MAX_VP, "dsrg_nav_logits_fwd: need G >= 1 and 1 <= Vp <= %d", NAV_MAX_VP);
   if (B <= 0) return DSRG_OK;
   hipLaunchKernelGGL(nav_logits_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited,
-                     vp_nav_masks, gmap_src, bw_mask, global_logits, local_logits, fused_logits, G, Vp);
+                     vp_nav_masks, gmap_src, bw_mask, global_logits, local_logits, fused_logits, o_raw, vp_obj_masks, obj_logits, G, Vp);
   DSRG_LAUNCH_CHECK("dsrg_nav_logits_fwd");
   return DSRG_OK;
 }

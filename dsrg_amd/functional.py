@@ -656,26 +656,35 @@ def attn_block_grouped(problems, nh, mask_mode, eps, p_attn=0.0, p_hid=0.0, spre
 FUSED_FFN = __import__('os').environ.get('DSRG_FUSED_FFN', '1') == '1'       # 0: linear + activation + linear_ln nodes (A/B)
 
 
-def ffn_grouped(problems, eps, p_drop=0.0, act=ACT_GELU):
-    """problems: list of (x, w1, b1, w2, b2, residual|None, gamma, beta) -> list of LN(drop(act(x W1^T + b1) W2^T + b2) + residual)."""
+def ffn_grouped(problems, eps, p_drop=0.0, act=ACT_GELU, outs=None, aux=None):
+    """problems: list of (x, w1, b1, w2, b2, residual|None, gamma, beta) -> list of LN(drop(act(x W1^T + b1) W2^T + b2) + residual).
+    outs / aux: output placement of the final LayerNorm (kernels.layernorm_grouped; inference only)."""
     flat = [t for p in problems for t in p]
     if FUSED_FFN and _needs_grad(flat) and all(p[1].shape[0] % 8 == 0 for p in problems):
+        _no_placement(outs, aux)
         return list(_FFNFn.apply(len(problems), eps, float(p_drop), act, *flat))
     inter = linear_grouped([(p[0], p[1], p[2], None) for p in problems], act=act)
-    return linear_ln_grouped([(h, p[3], p[4], p[5], p[6], p[7]) for h, p in zip(inter, problems)], eps, p_drop)
+    return linear_ln_grouped([(h, p[3], p[4], p[5], p[6], p[7]) for h, p in zip(inter, problems)], eps, p_drop, outs, aux)
 
 
-def linear_ln_grouped(problems, eps, p_drop=0.0):
-    """problems: list of (x, w, b, residual|None, gamma, beta) -> list of LN(drop(xW^T+b) + residual)."""
+def _no_placement(outs, aux):
+    if outs is not None or aux is not None:
+        raise _lib.DsrgHipError('output placement (outs / aux) is an inference-path feature: no gradient flows through it')
+
+
+def linear_ln_grouped(problems, eps, p_drop=0.0, outs=None, aux=None):
+    """problems: list of (x, w, b, residual|None, gamma, beta) -> list of LN(drop(xW^T+b) + residual).
+    outs / aux: output placement of the LayerNorm (kernels.layernorm_grouped; inference only)."""
     flat = [t for p in problems for t in p]
     if not _needs_grad(flat) and p_drop == 0.0:
         zs = K.gemm([(p[0], p[1], p[2], p[3]) for p in problems], ACT_NONE, True)
-        return K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, problems)], eps, problems[0][1].dtype)
+        return K.layernorm_grouped([(z, p[4], p[5], None) for z, p in zip(zs, problems)], eps, problems[0][1].dtype, outs=outs, aux=aux)
+    _no_placement(outs, aux)
     return list(_LinearLNFn.apply(len(problems), eps, float(p_drop), *flat))
 
 
-def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0):
-    return linear_ln_grouped([(x, w, b, residual, gamma, beta)], eps, p_drop)[0]
+def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0, out=None, aux=None):
+    return linear_ln_grouped([(x, w, b, residual, gamma, beta)], eps, p_drop, None if out is None else [out], None if aux is None else [aux])[0]
 
 
 # ----------------------------------------------------------------------------- attention
@@ -876,17 +885,19 @@ class _EmbedLnFn(torch.autograd.Function):
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
-             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, E1_padding_idx=None):
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, E1_padding_idx=None, seg=None):
     """Token-embedding sum + LayerNorm(s) (BertEmbeddings and the four visual token sites, see include/dsrg_hip.h).
     E1_padding_idx: row of E1 that receives no gradient (the word table is nn.Embedding(padding_idx=0) in the reference)."""
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
     ts = (base, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
     if _needs_grad(ts):
+        if seg is not None:
+            raise _lib.DsrgHipError('embed_ln: the gathered base (seg) is an inference-path feature')
         if base is not None and base.dim() != 2:
             base = base.reshape(M, H)
         return _EmbedLnFn.apply((M, H, dtype, device, idx1, idx2, eps, E1_padding_idx), base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
-    return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out)
+    return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out, seg)
 
 
 class _GroupMeanFn(torch.autograd.Function):
@@ -919,11 +930,14 @@ class _GaaPoolFn(torch.autograd.Function):
         return dx, dw.view(w.shape), db.view(b.shape)
 
 
-def gaa_pool(x, w, b):
-    """GAA (vilmodel.py:735-740): softmax_v(tanh(x_v.w + b))-weighted sum over the views; hand-written backward."""
+def gaa_pool(x, w, b, scatter=None):
+    """GAA (vilmodel.py:735-740): softmax_v(tanh(x_v.w + b))-weighted sum over the views; hand-written backward.
+    scatter = (buf [B,G,H], idx int64 [B]) (no-grad only): the pooled row also lands in buf[b, idx[b]]."""
     if _needs_grad((x, w, b)):
+        if scatter is not None:
+            raise _lib.DsrgHipError('gaa_pool: scatter is an inference-path placement (no gradient flows through it)')
         return _GaaPoolFn.apply(x if x.is_contiguous() else x.contiguous(), w, b)
-    return K.gaa_pool(x, w, b)
+    return K.gaa_pool(x, w, b, scatter)
 
 
 class _HeadTailFn(torch.autograd.Function):
@@ -970,11 +984,13 @@ class _NavLogitsFn(torch.autograd.Function):
         return dg, dl, df, None, None, None, None, None
 
 
-def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
-    """dynamic fusion weight, the three masked_fill_ and the logit-fusion loop (vilmodel.py:773-805) -> global, local, fused."""
-    if _needs_grad((g_raw, l_raw, fuse_raw)):
-        return _NavLogitsFn.apply(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
-    return K.nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask, o_raw=None, vp_obj_masks=None):
+    """dynamic fusion weight, the three masked_fill_ and the logit-fusion loop (vilmodel.py:773-805) -> global, local, fused
+    [, obj_logits = o_raw.masked_fill(~vp_obj_masks, -inf) (vilmodel_reverie.py:823-825): in the same launch without autograd]."""
+    if _needs_grad((g_raw, l_raw, fuse_raw, o_raw)):
+        out = _NavLogitsFn.apply(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask)
+        return out if o_raw is None else tuple(out) + (o_raw.masked_fill(vp_obj_masks.logical_not(), -float('inf')),)
+    return K.nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask, o_raw, vp_obj_masks)
 
 
 class _IglBlendFn(torch.autograd.Function):

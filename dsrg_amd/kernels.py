@@ -228,6 +228,11 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     _dev(q)
     B, Nq, _ = q.shape
     Nk = k.shape[1]
+    if isinstance(kmask, KeyLens):            # lengths instead of a mask tensor: the grouped entry carries them
+        if want_lse:
+            kmask = kmask.mask(Nk).contiguous()
+        else:
+            return attention_grouped([(q, k, v, kmask, dists)], nh, mask_mode, sprel_w, sprel_b, scale, p_drop, seed)[0]
     for t in (q, k, v):
         if t.stride(2) != 1 or t.dtype != q.dtype:
             raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes equal')
@@ -248,6 +253,23 @@ def attention(q, k, v, nh, kmask=None, mask_mode=_lib.MASK_NONE, dists=None, spr
     return (out, lse) if want_lse else out
 
 
+class KeyLens:
+    """Key validity given by lengths instead of a bool mask: key k of episode b is valid iff k % seg < lens[b, k // seg]
+    (lens int64 [B, ceil(Nk / seg)] or [B] with seg = Nk).  Accepted by attention_grouped in place of kmask (inference)."""
+    __slots__ = ('lens', 'seg', 'lens2')
+
+    def __init__(self, lens, seg, lens2=None):
+        self.lens, self.seg, self.lens2 = lens, int(seg), lens2      # lens2: optional second lengths tensor, added to the first
+
+    def mask(self, Nk):
+        """the bool [B, Nk] mask these lengths stand for (for the paths that need a tensor)"""
+        B = self.lens.shape[0]
+        nseg = (Nk + self.seg - 1) // self.seg
+        k = torch.arange(Nk, device=self.lens.device)
+        tot = self.lens if self.lens2 is None else self.lens + self.lens2
+        return (k % self.seg)[None] < tot.reshape(B, nseg)[:, k // self.seg]
+
+
 def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, sprel_b=None, scale=0.125, p_drop=0.0, seed=0):
     """problems: list (<= 4) of (q, k, v, kmask|None, dists|None) sharing B, nh, mask mode and dtype -> outputs, ONE launch."""
     lib = _lib.load()
@@ -265,9 +287,16 @@ def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, spre
             if t.stride(2) != 1 or t.dtype != q0.dtype or t.shape[0] != B:
                 raise _lib.DsrgHipError('attention: last dim must be contiguous, dtypes and batch equal')
         _check_heads(nh, q, k, v)
+        klens, kseg, klens2 = None, 0, None
+        if isinstance(kmask, KeyLens):       # validity from lengths (dsrg_attn_problem_t::klens): no mask tensor at all
+            klens, kseg, klens2, kmask = kmask.lens, kmask.seg, kmask.lens2, None
+            if klens2 is not None and (klens2.dtype != torch.int64 or not klens2.is_contiguous() or klens2.numel() != klens.numel()):
+                raise _lib.DsrgHipError('attention: KeyLens.lens2 must match lens')
+            if klens.dtype != torch.int64 or not klens.is_contiguous() or klens.numel() != B * ((Nk + kseg - 1) // kseg) or kseg < 1:
+                raise _lib.DsrgHipError('attention: KeyLens needs contiguous int64 lengths [B, ceil(Nk / seg)]')
         if kmask is not None and (kmask.dtype != torch.bool or kmask.shape != (B, Nk) or not kmask.is_contiguous()):
             raise _lib.DsrgHipError('attention: kmask must be contiguous bool [B,Nk]')
-        if (kmask is None) != (mask_mode == _lib.MASK_NONE):
+        if (kmask is None and klens is None) != (mask_mode == _lib.MASK_NONE):
             raise _lib.DsrgHipError('attention_grouped: kmask and mask_mode disagree')
         if dists is not None and (dists.dtype != torch.float32 or dists.shape != (B, Nq, Nk) or not dists.is_contiguous()):
             raise _lib.DsrgHipError('attention: pair_dists must be contiguous fp32 [B,Nq,Nk]')
@@ -279,6 +308,7 @@ def attention_grouped(problems, nh, mask_mode=_lib.MASK_NONE, sprel_w=None, spre
         a.q_bs, a.k_bs, a.v_bs, a.o_bs = bs(q), bs(k), bs(v), out.stride(0)
         a.q_rs, a.k_rs, a.v_rs, a.o_rs = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
         a.kmask, a.pair_dists, a.lse, a.Nq, a.Nk = _p(kmask), _p(dists), None, Nq, Nk
+        a.klens, a.kseg, a.klens2 = _p(klens), kseg, _p(klens2)
     _lib.check(lib.dsrg_attention_fwd_grouped(arr, n, mask_mode, _p(sprel_w), _p(sprel_b), B, nh, float(scale), float(p_drop), int(seed), _dt(q0),
                                               _stream()), 'dsrg_attention_fwd_grouped')
     return outs
@@ -357,10 +387,14 @@ def layernorm(x, gamma, beta, eps, residual=None, out_dtype=None, out=None):
     return out
 
 
-def layernorm_grouped(problems, eps, out_dtype=None, p_drop=0.0, seed=0):
+def layernorm_grouped(problems, eps, out_dtype=None, p_drop=0.0, seed=0, outs=None, aux=None):
     """problems: list of (x, gamma, beta, residual|None) with one H and one input dtype -> list of outputs, ONE launch.
     p_drop > 0: out = LN(dropout(x) + residual) with the counter-based mask of (seed, problem index, row, col)
-    (dsrg_layernorm_fwd_grouped_drop; layernorm_bwd recomputes it)."""
+    (dsrg_layernorm_fwd_grouped_drop; layernorm_bwd recomputes it).
+    outs: optional list (None = fresh) of destinations: a tensor with uniformly strided rows, or a 3-D [S, L, H] view whose
+    S segments of L rows are strided apart (dsrg_ln_problem_t::o_seg: e.g. slots 2.. of a [B, 38, H] token buffer).
+    aux: optional list (None = none) of (seg, t0, t1 | None): every seg-th row is also stored into row r // seg of the 2-D
+    views t0 / t1 (row 0 of every sequence into a concat buffer; the RMF memory into both [MEM] slots)."""
     lib = _lib.load()
     n = len(problems)
     if not 1 <= n <= _lib.MAX_GROUPS:
@@ -370,15 +404,30 @@ def layernorm_grouped(problems, eps, out_dtype=None, p_drop=0.0, seed=0):
     H = x0.shape[-1]
     out_dtype = out_dtype or (problems[0][3].dtype if problems[0][3] is not None else x0.dtype)
     arr = (_lib.LnProblem * n)()
-    outs = []
+    outs_in, outs = outs, []
     for i, (x, g, b, r) in enumerate(problems):
         if x.shape[-1] != H or x.dtype != x0.dtype:
             raise _lib.DsrgHipError('layernorm_grouped: problems must share H and dtype')
         M, ldx = _rows(x)
-        out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        out = outs_in[i] if (outs_in is not None and outs_in[i] is not None) else torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        if out.dtype != out_dtype or out.shape[-1] != H or out.numel() != M * H or out.stride(-1) != 1:
+            raise _lib.DsrgHipError('layernorm_grouped: destination must hold the %d x %d rows in the output dtype' % (M, H))
         outs.append(out)
         arr[i].x, arr[i].residual, arr[i].gamma, arr[i].beta, arr[i].out = _p(x), _p(r), _p(g), _p(b), _p(out)
-        arr[i].M, arr[i].ldx, arr[i].ldr, arr[i].ldo = M, ldx, (_rows(r)[1] if r is not None else 0), _rows(out)[1]
+        try:
+            ldo = _rows(out)[1]
+        except _lib.DsrgHipError:            # segments of rows strided apart
+            if out.dim() != 3:
+                raise
+            arr[i].o_seg, arr[i].o_seg_ld, ldo = out.shape[1], out.stride(0), out.stride(1)
+        arr[i].M, arr[i].ldx, arr[i].ldr, arr[i].ldo = M, ldx, (_rows(r)[1] if r is not None else 0), ldo
+        if aux is not None and aux[i] is not None:
+            seg, t0, t1 = aux[i]
+            for t in (t0, t1):
+                if t is not None and (t.dim() != 2 or t.shape != ((M + seg - 1) // seg, H) or t.stride(1) != 1 or t.dtype != out_dtype):
+                    raise _lib.DsrgHipError('layernorm_grouped: aux destinations must be 2-D [ceil(M / seg), H] views of the output dtype')
+            arr[i].aux_seg, arr[i].aux0, arr[i].aux1 = int(seg), _p(t0), _p(t1)
+            arr[i].aux_ld0, arr[i].aux_ld1 = (t0.stride(0) if t0 is not None else 0), (t1.stride(0) if t1 is not None else 0)
     if p_drop > 0.0:
         _lib.check(lib.dsrg_layernorm_fwd_grouped_drop(arr, n, H, float(eps), _dt(x0), _dt(outs[0]), float(p_drop), int(seed), _stream()),
                    'dsrg_layernorm_fwd_grouped_drop')
@@ -401,7 +450,10 @@ def _idx(t, M, what):
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
-             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None):
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, seg=None):
+    """seg = (base2 [B*No, H], T, V, No, lens0 int64 [B], lens1 int64 [B]): the base row of token t of episode b is gathered
+    from base (view rows, V per episode) / base2 (object rows, No per episode) / zero by the two lengths
+    (dsrg_embed_ln_fwd_seg)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(M, H, device=device, dtype=dtype)
@@ -417,6 +469,16 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
         raise _lib.DsrgHipError('embed_ln: base dtype must match out dtype')
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
+    if seg is not None:
+        base2, T_, V_, No_, l0, l1 = seg
+        B_ = M // T_
+        if base is None or base2.dtype != out.dtype or _rows(base)[0] != B_ * V_ or _rows(base2)[0] != B_ * No_ or \
+                any(t.dtype != torch.int64 or t.shape != (B_,) or not t.is_contiguous() for t in (l0, l1)):
+            raise _lib.DsrgHipError('embed_ln: seg needs base [B*V,H], base2 [B*No,H] of the output dtype and int64 lengths [B]')
+        _lib.check(lib.dsrg_embed_ln_fwd_seg(_p(base), ldb, _p(base2), _rows(base2)[1], T_, V_, No_, _p(l0), _p(l1), _p(feat), ldf, F_, _p(Wf), _p(bf),
+                                             _p(lnf_g), _p(lnf_b), _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),
+                                             float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd_seg')
+        return out
     _lib.check(lib.dsrg_embed_ln_fwd(_p(base), ldb, _p(feat), ldf, F_, _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b),
                                      _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),
                                      float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd')
@@ -437,14 +499,24 @@ def group_mean(x, G, out=None):
     return out
 
 
-def gaa_pool(x, w, b):
+def gaa_pool(x, w, b, scatter=None):
+    """x [B,V,H] (rows contiguous, batch stride free) -> pooled [B,H].  scatter = (buf [B,G,H], idx int64 [B]): the pooled row
+    of episode b is also stored into buf[b, idx[b]] (dsrg_gaa_pool_fwd_ex)."""
     lib = _lib.load()
     _dev(x)
-    if not x.is_contiguous():
-        raise _lib.DsrgHipError('gaa_pool: x must be contiguous [B,V,H]')
     B, V, H = x.shape
+    if x.stride(2) != 1 or x.stride(1) != H:
+        raise _lib.DsrgHipError('gaa_pool: x must be [B,V,H] with contiguous rows')
     out = torch.empty(B, H, device=x.device, dtype=x.dtype)
-    _lib.check(lib.dsrg_gaa_pool_fwd(_p(x), _p(w), _p(b), _p(out), B, V, H, _dt(x), _stream()), 'dsrg_gaa_pool_fwd')
+    buf = idx = None
+    if scatter is not None:
+        buf, idx = scatter
+        if buf.dim() != 3 or buf.shape[0] != B or buf.shape[2] != H or buf.stride(2) != 1 or buf.stride(1) != H or buf.dtype != x.dtype \
+                or idx.dtype != torch.int64 or idx.shape != (B,) or not idx.is_contiguous():
+            raise _lib.DsrgHipError('gaa_pool: scatter needs a [B,G,H] buffer of the input dtype with contiguous rows and int64 indices [B]')
+    xbs = x.stride(0) if B > 1 else V * H
+    _lib.check(lib.dsrg_gaa_pool_fwd_ex(_p(x), xbs, _p(w), _p(b), _p(out), _p(buf), (buf.stride(0) if buf is not None and B > 1 else (buf.shape[1] * H if buf is not None else 0)),
+                                        _p(idx), (buf.shape[1] if buf is not None else 0), B, V, H, _dt(x), _stream()), 'dsrg_gaa_pool_fwd_ex')
     return out
 
 
@@ -480,7 +552,8 @@ def head_tail_grouped(items, eps=1e-12):
     return outs
 
 
-def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask):
+def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, gmap_src, bw_mask, o_raw=None, vp_obj_masks=None):
+    """-> (global, local, fused logits[, obj_logits when o_raw / vp_obj_masks are given: REVERIE's masked object-grounding scores])"""
     lib = _lib.load()
     _dev(g_raw)
     B, G = g_raw.shape
@@ -489,6 +562,15 @@ def nav_logits(g_raw, l_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, g
         if not t.is_contiguous():
             raise _lib.DsrgHipError('nav_logits: inputs must be contiguous')
     gl, ll, fl = torch.empty_like(g_raw), torch.empty_like(l_raw), torch.empty_like(g_raw)
+    if o_raw is not None:
+        if o_raw.shape != l_raw.shape or o_raw.dtype != torch.float32 or not o_raw.is_contiguous() or vp_obj_masks.dtype != torch.bool \
+                or vp_obj_masks.shape != l_raw.shape or not vp_obj_masks.is_contiguous():
+            raise _lib.DsrgHipError('nav_logits: o_raw fp32 [B,Vp] and vp_obj_masks bool [B,Vp], contiguous')
+        ol = torch.empty_like(l_raw)
+        _lib.check(lib.dsrg_nav_logits_fwd_og(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gmap_masks), _p(gmap_visited), _p(vp_nav_masks), _p(gmap_src),
+                                              _p(bw_mask), _p(gl), _p(ll), _p(fl), _p(o_raw), _p(vp_obj_masks), _p(ol), B, G, Vp, _stream()),
+                   'dsrg_nav_logits_fwd_og')
+        return gl, ll, fl, ol
     _lib.check(lib.dsrg_nav_logits_fwd(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gmap_masks), _p(gmap_visited),
                                        _p(vp_nav_masks), _p(gmap_src), _p(bw_mask), _p(gl), _p(ll), _p(fl),
                                        B, G, Vp, _stream()), 'dsrg_nav_logits_fwd')

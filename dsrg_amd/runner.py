@@ -35,6 +35,11 @@ class GraphedNavStep:
         self.txt = txt_embeds.clone()
         self.txt_masks = txt_masks.clone()
         self.pano = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in pano_batch.items()}
+        # the 768-d image features are held in the compute dtype: the cast is paid once when a step's inputs are loaded
+        # (`runner.pano['view_img_fts'].copy_(fts)` converts), not by a kernel inside every replayed step
+        for k in ('view_img_fts',) + (('obj_img_fts',) if reverie else ()):
+            if isinstance(self.pano.get(k), torch.Tensor) and self.pano[k].is_floating_point():
+                self.pano[k] = self.pano[k].to(model.compute_dtype)
         self.nav = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in nav_batch.items()}
         B, G = self.nav['gmap_masks'].shape
         Vp = self.nav['vp_masks'].shape[1]
@@ -156,24 +161,37 @@ class GraphedNavStep:
             self.gmap_img[:, :g] = nav_inputs['gmap_img_embeds'].to(self.gmap_img.dtype)
             self.gmap_img[:, 1] = mem
 
-    def _pano_body(self):
-        pe, pm, pf = self.model('panorama', self.pano)
-        self.vp_img[:, 2:] = pe
+    # No copy kernels between the calls: the panorama call's last LayerNorm stores its tokens straight into slots 2.. of the
+    # viewpoint-token buffer (`pano_out`), the GAA kernel also stores the pooled embedding into the current node's graph-map
+    # slot (`gmap_scatter`), the RMF LayerNorm also stores the memory into both [MEM] slots (`mem_out`), and the attention
+    # kernels form the length masks themselves (`want_pano_masks=False`; pano_masks() builds the tensor on demand).
+    def _pano_body(self, scatter=False):
+        pb = dict(self.pano)
+        pb.update(pano_out=self.vp_img[:, 2:], want_pano_masks=False)
+        if scatter:
+            pb['gmap_scatter'] = (self.gmap_img, self.cur_gmap_idx)
+        pe, pm, pf = self.model('panorama', pb)
         self.pano_out = (pe, pm, pf)
+
+    def pano_masks(self):
+        """bool [B, T] validity of the panorama tokens of the current inputs (the panorama call's second return value)"""
+        lens = self.pano['view_lens']
+        if self.reverie and self.pano.get('obj_lens') is not None and self.pano.get('obj_img_fts') is not None:
+            lens = lens + self.pano['obj_lens']
+        T = self.vp_img.shape[1] - 2
+        return torch.arange(T, device=lens.device)[None] < lens[:, None]
 
     def _nav_body(self):
         nb = dict(self.nav)
         nb.update(vp_img_embeds=self.vp_img, gmap_img_embeds=self.gmap_img,
-                  txt_embeds=self.txt, txt_masks=self.txt_masks, txt_kv=self.kv)
+                  txt_embeds=self.txt, txt_masks=self.txt_masks, txt_kv=self.kv,
+                  mem_out=(self.vp_img[:, 1], self.gmap_img[:, 1]))
         o = self.model('navigation', nb)
-        self.vp_img[:, 1] = o['cls_embeds']
-        self.gmap_img[:, 1] = o['cls_embeds']
         pe, pm, pf = self.pano_out
         self.out = {'pano_embeds': pe, 'pano_fused': pf, **o}
 
     def _body(self):
-        self._pano_body()
-        self.gmap_img[self._rows, self.cur_gmap_idx] = self.pano_out[2]
+        self._pano_body(scatter=True)
         self._nav_body()
 
     def _run(self, graph, fn):

@@ -453,7 +453,10 @@ class GlocalTextPathNavCMT(nn.Module):
                         bf=W['obj.bbox.b'], E1=W['obj.name'], idx1=fts.view(B * V * O, -1)[:, -1],
                         E2=W['obj.nav'], idx2=(nav_types.reshape(-1), O),
                         lno=(W['obj.ln.g'], W['obj.ln.b'])).view(B, V * O, d)
-        valid = (_arange(O, fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
+        if not torch.is_grad_enabled() and lens.dtype == torch.int64:
+            valid = K.KeyLens(lens.reshape(B, V).contiguous(), O)      # the attention kernel forms the mask from the lengths
+        else:
+            valid = (_arange(O, fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
         for i in range(2):
             e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
         return e.reshape(B * V * O, d), O
@@ -479,13 +482,17 @@ class GlocalTextPathNavCMT(nn.Module):
                 x = Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b'], residual=x)
         return x
 
-    def _pano_tokens(self, W, base, loc_fts, nav_types):
+    def _pano_tokens(self, W, base, loc_fts, nav_types, seg=None):
+        """seg (inference, REVERIE): (object rows [B*No, H], No, view_lens, obj_lens) - the per-episode token assembly
+        [views[:vl] ; objects[:ol] ; zero pad] is done by the embedding kernel's base-row gather (kernels.embed_ln)"""
         cfg = self.config
-        B, T, H = base.shape
-        x = Fn.embed_ln(B * T, H, self.compute_dtype, base.device, base=base.reshape(B * T, H),
+        B, V, H = base.shape
+        T = loc_fts.shape[1]
+        x = Fn.embed_ln(B * T, H, self.compute_dtype, base.device, base=base.reshape(B * V, H),
                         feat=loc_fts.float().reshape(B * T, -1).contiguous(), Wf=W['loc.w'], bf=W['loc.b'],
                         lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=nav_types.reshape(-1),
-                        vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b'])).view(B, T, H)
+                        vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b']),
+                        seg=None if seg is None else (seg[0], T, V, seg[1], seg[2], seg[3])).view(B, T, H)
         # FT REVERIE: nn.Dropout(config.image_dropout_prob) (vilmodel_reverie.py:588); R2R and both pre-training twins:
         # hidden_dropout_prob (vilmodel.py:576, PT/vilmodel_reverie.py:514)
         ft_reverie = self.REVERIE and not self.PRETRAIN
@@ -530,23 +537,37 @@ class GlocalTextPathNavCMT(nn.Module):
             return r
         return join
 
-    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
-        """R2R: vilmodel.py:690-742."""
+    def _len_masks(self, lens, T, want_masks, lens2=None):
+        """(key-validity operand of the attention launch, bool mask [B,T] or None): without autograd the attention kernel
+        forms the mask from the lengths (no compare kernel); the tensor is built only when the caller wants it back."""
+        dev = lens.device
+        tot = lens if lens2 is None else lens + lens2
+        lazy = not torch.is_grad_enabled() and lens.dtype == torch.int64 and (lens2 is None or lens2.dtype == torch.int64)
+        masks = (_arange(T, dev)[None] < tot[:, None]) if (want_masks or not lazy) else None
+        if lazy:
+            return K.KeyLens(lens.contiguous(), T, None if lens2 is None else lens2.contiguous()), masks
+        return masks.contiguous(), masks
+
+    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens,
+                                  pano_out=None, gmap_scatter=None, want_masks=True):
+        """R2R: vilmodel.py:690-742.  Extensions for a serving loop (dsrg_amd.runner; inference only): pano_out = a [B,V,H]
+        view (rows contiguous, batch stride free) that receives pano_embeds, gmap_scatter = (buffer [B,G,H], idx int64 [B]) that
+        also receives the pooled embedding at row idx[b], want_masks=False returns None for pano_masks."""
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, V, _ = view_img_fts.shape
         H, d = cfg.hidden_size, cfg.obj_v2_size
         objs = self._fork(lambda: self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types))
         img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
         x = self._pano_tokens(W, img, loc_fts, nav_types)
-        pano_masks = _arange(V, x.device)[None] < view_lens[:, None]
-        x = self._pano_encoder(W, x, pano_masks.contiguous())
+        km, pano_masks = self._len_masks(view_lens, V, want_masks)
+        x = self._pano_encoder(W, x, km)
         obj_rows, O = objs()
         g, b = W['pano.norm.g'], W['pano.norm.b']
         cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
                             lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
                             B, V, H, d, x.device)
-        pano = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12)
-        fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'])
+        pano = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out=pano_out)
+        fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'], scatter=gmap_scatter)
         return pano, pano_masks, fused
 
     # ---------------------------------------------------------------- navigation (vilmodel.py:745-830)
@@ -607,7 +628,7 @@ class GlocalTextPathNavCMT(nn.Module):
             F[k] = (wf, wf.float().sum(1).contiguous(), (W[lin_key + '.b'] + w.float() @ b).contiguous())
         return F[k]
 
-    def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs):
+    def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs, final_aux=None):
         """(generator: yields after every launch, returns the result - see _x_layers_gen)
         _x_layers without its 3 LayerNorm launches per layer and branch (inference).  A post-LN sub-block leaves its
         UN-normalised sum y (compute dtype) plus per-row partial statistics written by the same GEMM launch; the projections
@@ -674,30 +695,31 @@ class GlocalTextPathNavCMT(nn.Module):
             if i == nl - 1:
                 z = dense_res('.ff2', inter, None, out_f32=True)
                 yield
-                return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd)
+                return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd, aux=final_aux)
             st = new_stats()
             y = dense_res('.ff2', inter, st)
             yield
             cur = [(y[j], st[j], ks[j] + '.fln') for j in range(n)]
 
-    def _x_layers(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
+    def _x_layers(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l'), final_aux=None):
         """The CrossmodalEncoders of the branches in `brs` (global 'g', local 'l') in lock-step: every GEMM is one
-        grouped launch over the branches (vilmodel.py:540-549, 454-469)."""
-        g = self._x_layers_gen(W, kv, txt_masks, feats, masks, dists, brs)
+        grouped launch over the branches (vilmodel.py:540-549, 454-469).  final_aux: per branch, the aux placement of the last
+        LayerNorm (kernels.layernorm_grouped; inference only)."""
+        g = self._x_layers_gen(W, kv, txt_masks, feats, masks, dists, brs, final_aux)
         while True:
             try:
                 next(g)
             except StopIteration as e:
                 return e.value
 
-    def _x_layers_gen(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l')):
+    def _x_layers_gen(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l'), final_aux=None):
         """_x_layers as a generator that yields between its launches and returns the result: the two-stream schedule
         (_x_layers_two_streams) advances the global and the local branch in turn, so that their nodes enter the captured HIP
         graph interleaved - hipGraphLaunch submits kernel nodes in creation order, and a branch captured as a whole after the
         other one starts several hundred microseconds late."""
         cfg = self.config
         if self.fuse_ln and not torch.is_grad_enabled() and not self.training and cfg.hidden_size % 64 == 0 and cfg.hidden_size <= 1024:
-            return (yield from self._x_layers_fused_gen(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs))
+            return (yield from self._x_layers_fused_gen(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs, final_aux))
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
@@ -714,11 +736,12 @@ class GlocalTextPathNavCMT(nn.Module):
                                           nh, MASK_NEG10000, eps, self._attn_p(), ph, sw, sb)
             yield
             feats = Fn.ffn_grouped([(feats[j], W[ks[j] + '.ff1.w'], W[ks[j] + '.ff1.b'], W[ks[j] + '.ff2.w'], W[ks[j] + '.ff2.b'], feats[j],
-                                     W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b']) for j in range(n)], eps, self.config.hidden_dropout_prob if self.training else 0.0)
+                                     W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b']) for j in range(n)], eps, self.config.hidden_dropout_prob if self.training else 0.0,
+                                   aux=final_aux if i == nl - 1 else None)
             yield
         return feats
 
-    def _x_layers_two_streams(self, W, kv, tm, g, v, gmask, vmask, dists):
+    def _x_layers_two_streams(self, W, kv, tm, g, v, gmask, vmask, dists, final_aux=None):
         """Global branch on the current stream, local branch on the side stream, advanced in turn (no-grad mode only)."""
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
@@ -727,8 +750,9 @@ class GlocalTextPathNavCMT(nn.Module):
         if side is None:
             side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
         side.wait_stream(cur)
-        gens = [(side, self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',))),
-                (cur, self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',)))]
+        fa = final_aux or [None, None]
+        gens = [(side, self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',), final_aux=[fa[1]])),
+                (cur, self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',), final_aux=[fa[0]]))]
         res, live = [None, None], [0, 1]
         self._fork_depth += 1
         try:
@@ -756,8 +780,9 @@ class GlocalTextPathNavCMT(nn.Module):
         h = Fn.linear_grouped([(x, W[k + '.l1.w'], W[k + '.l1.b'], None) for k, x in items], act=ACT_RELU, out_f32=True)
         return Fn.head_tail_grouped([(h[j], W[k + '.ln.g'], W[k + '.ln.b'], W[k + '.w2'], W[k + '.b2']) for j, (k, _) in enumerate(items)])
 
-    def _rmf(self, W, g, v, txt):
-        """RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN"""
+    def _rmf(self, W, g, v, txt, mem_out=None):
+        """RMF (vilmodel.py:815-818): three poolers on row 0 of each sequence -> his_map -> LN.  mem_out = (t0, t1 | None):
+        [B,H] views (e.g. the [MEM] slots of the next step's token buffers) that also receive the result (inference only)."""
         cfg, cd = self.config, self.compute_dtype
         B, H, dev = g.shape[0], cfg.hidden_size, g.device
         rows = [g[:, 0], v[:, 0], txt[:, 0]]
@@ -768,15 +793,17 @@ class GlocalTextPathNavCMT(nn.Module):
             pooled = torch.empty(B, 3 * H, device=dev, dtype=cd)
             K.gemm([(rows[j], W[keys[j] + '.w'], W[keys[j] + '.b'], None) for j in range(3)], ACT_TANH,
                    outs=[pooled[:, j * H:(j + 1) * H] for j in range(3)])
-        return Fn.linear_ln(pooled, W['his.map.w'], W['his.map.b'], W['his.ln.g'], W['his.ln.b'], cfg.layer_norm_eps)
+        return Fn.linear_ln(pooled, W['his.map.w'], W['his.map.b'], W['his.ln.g'], W['his.ln.b'], cfg.layer_norm_eps,
+                            aux=None if mem_out is None else (1, mem_out[0], mem_out[1] if len(mem_out) > 1 else None))
 
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
                                     gmap_masks, gmap_pair_dists, gmap_visited_masks, gmap_vpids,
                                     vp_img_embeds, vp_pos_fts, vp_masks, vp_nav_masks, vp_obj_masks, vp_cand_vpids,
-                                    gmap_src=None, bw_mask=None, txt_kv=None):
+                                    gmap_src=None, bw_mask=None, txt_kv=None, mem_out=None):
         """Extension keys (optional, not in the reference): `gmap_src`/`bw_mask` = precomputed fusion_indices()
         on the device, `txt_kv` = precomputed text_kv(txt_embeds); with them the call does no host work and
-        can be captured in a HIP graph (dsrg_amd.runner)."""
+        can be captured in a HIP graph (dsrg_amd.runner).  `mem_out` = (t0[, t1]): [B,H] views that also receive cls_embeds
+        (the [MEM] slots of the next step's token buffers, agent.py:185-188, 234-237; inference only)."""
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, G, H = gmap_img_embeds.shape
         Vp = vp_img_embeds.shape[1]
@@ -795,6 +822,12 @@ class GlocalTextPathNavCMT(nn.Module):
         v = vj()
         dists = gmap_pair_dists.float().contiguous() if self.global_encoder.sprel_linear is not None else None
         kv = txt_kv if txt_kv is not None else self._text_kv(W, txt)
+        # [g0 | v0] for sap_fuse_linear (vilmodel.py:773): without autograd the last LayerNorm of each branch also stores its
+        # row 0 of every episode into one [B, 2H] buffer (no concat kernel)
+        cls2 = final_aux = None
+        if self.sap_fuse_linear is not None and not torch.is_grad_enabled():
+            cls2 = torch.empty(B, 2 * H, device=dev, dtype=cd)
+            final_aux = [(G, cls2[:, :H], None), (Vp, cls2[:, H:], None)]
         # two streams pay at R2R's 20 vs 38 tokens and, with round 2's 64x64x3 GEMM plan, at REVERIE's 20 vs 58 too
         # (bench.py --config c3: 1.762 ms grouped, 1.649 ms split; round 1's plan had it the other way round); beyond a
         # 4:1 imbalance the grouped launches are kept
@@ -803,30 +836,30 @@ class GlocalTextPathNavCMT(nn.Module):
         if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
                 and max(G, Vp) <= self.split_max_ratio * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
             if self.interleave_branches:
-                g, v = self._x_layers_two_streams(W, kv, tm, g, v, gmap_masks.contiguous(), vp_masks.contiguous(), dists)
+                g, v = self._x_layers_two_streams(W, kv, tm, g, v, gmap_masks.contiguous(), vp_masks.contiguous(), dists, final_aux)
             else:
-                lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',))[0])
-                g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',))[0]
+                lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',), final_aux=final_aux and [final_aux[1]])[0])
+                g = self._x_layers(W, kv, tm, [g], [gmap_masks.contiguous()], dists, brs=('g',), final_aux=final_aux and [final_aux[0]])[0]
                 v = lj()
         else:
-            g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists)
+            g, v = self._x_layers(W, kv, tm, [g, v], [gmap_masks.contiguous(), vp_masks.contiguous()], dists, final_aux=final_aux)
 
         items = [('head.g', g), ('head.l', v)]
         if self.sap_fuse_linear is not None:
-            items.append(('head.f', torch.cat([g[:, 0], v[:, 0]], 1)))
+            items.append(('head.f', cls2 if cls2 is not None else torch.cat([g[:, 0], v[:, 0]], 1)))
         if vp_obj_masks is not None:
             items.append(('head.o', v))
-        rmf = self._fork(lambda: self._rmf(W, g, v, txt))          # RMF poolers beside the SAP heads
+        rmf = self._fork(lambda: self._rmf(W, g, v, txt, mem_out))          # RMF poolers beside the SAP heads
         sc = self._heads(W, items)
         fuse_raw = sc[2] if self.sap_fuse_linear is not None else None
         if gmap_src is None:
             src_np, bw_np = self.fusion_indices(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, Vp, 2)
             gmap_src, bw_mask = torch.from_numpy(src_np).to(dev), torch.from_numpy(bw_np).to(dev)
-        gl, ll, fl = Fn.nav_logits(sc[0], sc[1], fuse_raw, gmap_masks.contiguous(), gmap_visited_masks.contiguous(),
-                                   vp_nav_masks.contiguous(), gmap_src, bw_mask)
-        obj_logits = None
-        if vp_obj_masks is not None:
-            obj_logits = sc[-1].masked_fill(vp_obj_masks.logical_not(), -float('inf'))
+        res = Fn.nav_logits(sc[0], sc[1], fuse_raw, gmap_masks.contiguous(), gmap_visited_masks.contiguous(),
+                            vp_nav_masks.contiguous(), gmap_src, bw_mask, sc[-1] if vp_obj_masks is not None else None,
+                            vp_obj_masks.contiguous() if vp_obj_masks is not None else None)
+        gl, ll, fl = res[:3]
+        obj_logits = res[3] if vp_obj_masks is not None else None
 
         cls = rmf()
         return {'gmap_embeds': g, 'vp_embeds': v, 'global_logits': gl, 'local_logits': ll, 'fused_logits': fl,
@@ -838,8 +871,11 @@ class GlocalTextPathNavCMT(nn.Module):
             return self.forward_text(batch['txt_ids'], batch['txt_masks'], batch['act_txt_ids'], batch['act_txt_masks'],
                                      batch['obj_txt_ids'], batch['obj_txt_masks'])
         elif mode == 'panorama':
+            get = batch.get if hasattr(batch, 'get') else (lambda k, d=None: batch[k])
             return self.forward_panorama_per_step(batch['view_img_fts'], batch['obj_img_fts'], batch['loc_fts'],
-                                                  batch['nav_types'], batch['view_lens'], batch['obj_lens'])
+                                                  batch['nav_types'], batch['view_lens'], batch['obj_lens'],
+                                                  pano_out=get('pano_out'), gmap_scatter=get('gmap_scatter'),
+                                                  want_masks=get('want_pano_masks', True) is not False)
         elif mode == 'navigation':
             get = batch.get if hasattr(batch, 'get') else (lambda k, d=None: batch[k])
             return self.forward_navigation_per_step(
@@ -847,4 +883,4 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch['gmap_pos_fts'], batch['gmap_masks'], batch['gmap_pair_dists'], batch['gmap_visited_masks'],
                 batch['gmap_vpids'], batch['vp_img_embeds'], batch['vp_pos_fts'], batch['vp_masks'],
                 batch['vp_nav_masks'], batch['vp_obj_masks'], batch['vp_cand_vpids'],
-                gmap_src=get('gmap_src'), bw_mask=get('bw_mask'), txt_kv=get('txt_kv'))
+                gmap_src=get('gmap_src'), bw_mask=get('bw_mask'), txt_kv=get('txt_kv'), mem_out=get('mem_out'))

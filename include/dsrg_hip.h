@@ -138,6 +138,13 @@ typedef struct {
   const float* pair_dists;          /* [B,Nq,Nk] or NULL */
   float* lse;                       /* [B,NH,Nq] or NULL */
   int32_t Nq, Nk;
+  /* Key validity from lengths instead of kmask (ABI v12; kmask must then be NULL): key k of episode b is valid iff
+   * k % kseg < klens[b, k / kseg], klens int64 [B, ceil(Nk / kseg)].  kseg = Nk: one length per episode (gen_seq_masks,
+   * FT/ops.py:35-43: the panorama's view_lens); kseg = O: one length per view for the V*O object tokens (obj_lens,
+   * FT/vilmodel.py:711).  The reference builds these masks with an arange < len comparison per call. */
+  const int64_t* klens;
+  int32_t kseg;
+  const int64_t* klens2;            /* optional, same shape: the limit is klens + klens2 (REVERIE: views + objects per episode) */
 } dsrg_attn_problem_t;
 int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems /*host*/, int nproblems, int mask_mode,
                                const float* sprel_w, const float* sprel_b, int B, int NH, float scale, float p_drop,
@@ -161,6 +168,17 @@ typedef struct {
   const float* beta;
   void* out;            /* [M,H], leading dim ldo */
   int32_t M, ldx, ldr, ldo;
+  /* Optional output placement (ABI v12; all 0 / NULL = plain), so that a serving loop needs no copy kernels between calls
+   * (the reference's agent builds the next call's token buffers with torch.cat / slot assignments, FT/r2r/agent.py:231-237,
+   * 185-188, 472; FT/vilmodel.py:773 concatenates the two [CLS] rows for sap_fuse_linear):
+   *  - o_seg > 0: rows come in segments of o_seg rows; row r is stored at out + (r / o_seg) * o_seg_ld + (r % o_seg) * ldo
+   *    (e.g. the 36 panorama tokens of episode b into slots 2.. of a [B, 38, H] viewpoint-token buffer);
+   *  - aux_seg > 0: every aux_seg-th row (r % aux_seg == 0) is ALSO stored at aux0 + (r / aux_seg) * aux_ld0 and / or
+   *    aux1 + (r / aux_seg) * aux_ld1 (NULL = skip): row 0 of every sequence into a [B, 2H] concat buffer, the RMF memory
+   *    into the [MEM] slots of both token buffers. */
+  int32_t o_seg, o_seg_ld;
+  void* aux0; void* aux1;
+  int32_t aux_seg, aux_ld0, aux_ld1, reserved_;
 } dsrg_ln_problem_t;
 int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems /*host*/, int nproblems, int H, float eps,
                                int in_dtype, int out_dtype, void* stream);
@@ -191,12 +209,34 @@ int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, int ldf, int
 int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, int M, int G, int H, int dtype,
                         void* stream);
 
+/* dsrg_embed_ln_fwd with the base row GATHERED from two tables by per-episode lengths (REVERIE's per-episode token
+ * assembly, FT/vilmodel_reverie.py:727-735: a Python loop of torch.cat / zero padding): rows come in episodes of seg_T
+ * tokens; token t of episode b takes its base row from  base[b*seg_V + t]  if t < lens0[b],  from
+ * base2[b*seg_No + (t - lens0[b])]  if t < lens0[b] + lens1[b],  and is zero otherwise.  lens0 / lens1 int64 [B];
+ * base2 has leading dim ldb2.  seg_T = 0: plain dsrg_embed_ln_fwd. */
+int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
+                          const int64_t* lens0, const int64_t* lens1,
+                          const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                          const float* lnf_gamma, const float* lnf_beta,
+                          const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                          const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                          const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                          void* out, int ldo, int M, int H, int dtype, void* stream);
+
 /* ---- GAA: global adaptive aggregation of the panorama ---------------------------------------------
  * a[b,v] = softmax_v( tanh( x[b,v,:]·w + bias ) ) over ALL V slots (unmasked);
  * out[b,:] = sum_v a[b,v]·x[b,v,:].  FT/vilmodel.py:735-740 (REVERIE vilmodel_reverie.py:753-758).
  * x is [B,V,H] contiguous in `dtype`, w fp32 [H], bias fp32 [1], out [B,H] `dtype`; V <= 64. */
 int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* out, int B, int V,
                       int H, int dtype, void* stream);
+/* The same with placement for a serving loop (no copy kernels between the panorama and the navigation call): x is read with
+ * a batch stride x_bs (elements; the panorama tokens as they lie in slots 2.. of the viewpoint-token buffer), and the pooled
+ * row is ALSO stored at out2 + b*out2_bs + idx2[b]*H (NULL = skip): the current node's slot of the graph-map token buffer
+ * (FT/r2r/agent.py:443-447 writes the GAA-pooled panorama into the graph map).  idx2 int64 [B] with 0 <= idx2[b] < idx2_max
+ * (the caller's guarantee; out2_bs >= idx2_max*H is checked). */
+int dsrg_gaa_pool_fwd_ex(const void* x, int64_t x_bs, const float* w, const float* bias, void* out, void* out2,
+                         int64_t out2_bs, const int64_t* idx2, int idx2_max, int B, int V, int H, int dtype,
+                         void* stream);
 
 /* ---- ClsPrediction tail: score[r] = LN(h[r,:])·w2 + b2 ---------------------------------------------
  * h = relu(Linear(x)) comes from dsrg_gemm_nt (fp32, DSRG_ACT_RELU).  FT/vilmodel.py:616-628
@@ -225,6 +265,14 @@ int dsrg_nav_logits_fwd(const float* g_raw, const float* l_raw, const float* fus
                         const uint8_t* gmap_masks, const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
                         const int32_t* gmap_src, const uint8_t* bw_mask, float* global_logits,
                         float* local_logits, float* fused_logits, int B, int G, int Vp, void* stream);
+/* The same plus the object-grounding logits of REVERIE in the same launch (FT/vilmodel_reverie.py:823-825:
+ * obj_logits = og_head(vp_embeds).masked_fill(~vp_obj_masks, -inf)): o_raw fp32 [B,Vp], vp_obj_masks bool [B,Vp],
+ * obj_logits fp32 [B,Vp]; all three NULL = dsrg_nav_logits_fwd. */
+int dsrg_nav_logits_fwd_og(const float* g_raw, const float* l_raw, const float* fuse_raw,
+                           const uint8_t* gmap_masks, const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
+                           const int32_t* gmap_src, const uint8_t* bw_mask, float* global_logits,
+                           float* local_logits, float* fused_logits, const float* o_raw, const uint8_t* vp_obj_masks,
+                           float* obj_logits, int B, int G, int Vp, void* stream);
 
 /* ---- action selection + loss tail of a rollout step -------------------------------
  * One pass over the nav logits [B,N] (fp32, -inf = masked) replaces FT/r2r/agent.py:484 (softmax), :491 (stop

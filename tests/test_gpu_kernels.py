@@ -990,3 +990,109 @@ def test_attention_block_fused_node_matches_separate_nodes(K, dtype, cross, p_hi
     for idx, (a, b) in enumerate(zip(outs[0], outs[1])):
         assert a is not None and b is not None, idx
         assert (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item()), idx
+
+
+# ----------------------------------------------------------------------------- round 3: output placement / length masks (no glue kernels)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layernorm_output_placement(K, dtype):
+    """dsrg_ln_problem_t o_seg / aux: segments of rows stored into slots 2.. of a larger token buffer, every seg-th row also
+    into two more destinations, next to a plain problem in the same launch - all equal to the plain launch's rows."""
+    B, V, Vp, H = 5, 36, 38, 768
+    x, x2 = _r(B * V, H), _r(7, H, seed=1)
+    g, b = 1 + 0.2 * _r(H, seed=2), 0.1 * _r(H, seed=3)
+    ref, ref2 = K.layernorm_grouped([(x, g, b, None), (x2, g, b, None)], 1e-12, dtype)
+    buf = torch.full((B, Vp, H), 7.0, device='cuda', dtype=dtype)
+    cat = torch.zeros(B, 2 * H, device='cuda', dtype=dtype)
+    mem = torch.zeros(B, 20, H, device='cuda', dtype=dtype)
+    out, out2 = K.layernorm_grouped([(x, g, b, None), (x2, g, b, None)], 1e-12, dtype, outs=[buf[:, 2:], None],
+                                    aux=[(V, cat[:, H:], mem[:, 1]), None])
+    assert out.data_ptr() == buf[:, 2:].data_ptr()
+    assert torch.equal(buf[:, 2:].reshape(B * V, H), ref) and torch.equal(out2, ref2)
+    assert (buf[:, :2] == 7.0).all()                                        # the other slots are untouched
+    assert torch.equal(cat[:, H:], ref.view(B, V, H)[:, 0]) and (cat[:, :H] == 0).all()
+    assert torch.equal(mem[:, 1], ref.view(B, V, H)[:, 0]) and (mem[:, 0] == 0).all() and (mem[:, 2:] == 0).all()
+    # aux with seg = 1 (every row): the RMF memory into both [MEM] slots
+    y = _r(B, H, seed=4)
+    r1 = K.layernorm_grouped([(y, g, b, None)], 1e-12, dtype)[0]
+    K.layernorm_grouped([(y, g, b, None)], 1e-12, dtype, aux=[(1, buf[:, 1], mem[:, 3])])
+    assert torch.equal(buf[:, 1], r1) and torch.equal(mem[:, 3], r1) and torch.equal(buf[:, 2:].reshape(B * V, H), ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gaa_pool_strided_input_and_scatter(K, dtype):
+    B, V, G, H = 6, 36, 9, 768
+    buf = _r(B, V + 2, H, dtype=dtype)
+    w, b = _r(H, seed=1, scale=0.05), _r(1, seed=2)
+    ref = K.gaa_pool(buf[:, 2:].contiguous(), w, b)
+    gm = torch.zeros(B, G, H, device='cuda', dtype=dtype)
+    idx = torch.tensor([2, 8, 3, 2, 5, 7], device='cuda')
+    got = K.gaa_pool(buf[:, 2:], w, b, scatter=(gm, idx))
+    assert torch.equal(got, ref)
+    want = torch.zeros_like(gm)
+    want[torch.arange(B, device='cuda'), idx] = ref
+    assert torch.equal(gm, want)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('mode', [1, 2, 3])
+def test_attention_key_lengths_equal_masks(K, dtype, mode):
+    """dsrg_attn_problem_t klens / kseg / klens2: validity from lengths is bit-identical to the bool mask they stand for
+    (one length per episode; one per view for the V*O object tokens; the sum of two lengths)."""
+    B, nh, V, O = 5, 2, 36, 3
+    q, k, v = (_r(B, V * O, nh * 64, seed=s, dtype=dtype) for s in range(3))
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(0, O + 1, (B, V), generator=g).cuda()
+    lens[:, 0] = O                                               # (-inf mode: never a fully masked row)
+    kl = K.KeyLens(lens.contiguous(), O)
+    mask = (torch.arange(O, device='cuda')[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
+    assert torch.equal(kl.mask(V * O), mask)
+    ref = K.attention(q, k, v, nh, mask, mode)
+    assert torch.equal(K.attention(q, k, v, nh, kl, mode), ref)
+    # one length per episode, two problems in one launch, the second with the sum of two lengths
+    Nk = 56
+    k2, v2 = _r(B, Nk, nh * 64, seed=7, dtype=dtype), _r(B, Nk, nh * 64, seed=8, dtype=dtype)
+    l0 = torch.tensor([36, 30, 36, 1, 20], device='cuda')
+    l1 = torch.tensor([20, 0, 3, 0, 11], device='cuda')
+    m1 = (torch.arange(V * O, device='cuda')[None] < (l0 * 2)[:, None]).contiguous()
+    m2 = (torch.arange(Nk, device='cuda')[None] < (l0 + l1)[:, None]).contiguous()
+    r = K.attention_grouped([(q, k, v, m1, None), (q[:, :40], k2, v2, m2, None)], nh, mode)
+    o = K.attention_grouped([(q, k, v, K.KeyLens((l0 * 2).contiguous(), V * O), None), (q[:, :40], k2, v2, K.KeyLens(l0, Nk, l1), None)], nh, mode)
+    assert torch.equal(o[0], r[0]) and torch.equal(o[1], r[1])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_embed_ln_gathered_base(K, dtype):
+    """dsrg_embed_ln_fwd_seg: REVERIE's per-episode [views[:vl] ; objects[:ol] ; zero pad] inside the token-embedding kernel
+    against the same launch on a torch.gather-ed base."""
+    B, V, No, H, F = 7, 36, 20, 768, 7
+    T = V + No
+    view, o1 = _r(B * V, H, dtype=dtype), _r(B * No, H, seed=1, dtype=dtype)
+    vl = torch.tensor([36, 36, 30, 36, 1, 36, 20], device='cuda')
+    ol = torch.tensor([20, 0, 5, 13, 0, 1, 20], device='cuda')
+    feat, Wf, bf = _r(B * T, F, seed=2), _r(H, F, seed=3, scale=0.3), _r(H, seed=4, scale=0.1)
+    lg, lb, og, ob = 1 + 0.1 * _r(H, seed=5), 0.1 * _r(H, seed=6), 1 + 0.1 * _r(H, seed=7), 0.1 * _r(H, seed=8)
+    E1 = _r(3, H, seed=9)
+    idx = torch.randint(0, 3, (B * T,), generator=torch.Generator().manual_seed(1)).cuda()
+    vec = _r(H, seed=10)
+    pos = torch.arange(T, device='cuda')[None]
+    sel = torch.where(pos < vl[:, None], pos, torch.where(pos < (vl + ol)[:, None], V + pos - vl[:, None], torch.full_like(pos, V + No)))
+    src = torch.cat([view.view(B, V, H), o1.view(B, No, H), torch.zeros(B, 1, H, device='cuda', dtype=dtype)], 1)
+    base = torch.gather(src, 1, sel[..., None].expand(B, T, H)).reshape(B * T, H).contiguous()
+    kw = dict(feat=feat, Wf=Wf, bf=bf, lnf=(lg, lb), E1=E1, idx1=idx, vec=vec, lno=(og, ob))
+    ref = K.embed_ln(B * T, H, dtype, 'cuda', base=base, **kw)
+    got = K.embed_ln(B * T, H, dtype, 'cuda', base=view, seg=(o1, T, V, No, vl, ol), **kw)
+    assert torch.equal(got, ref)
+
+
+def test_nav_logits_with_object_grounding(K):
+    B, G, Vp = 6, 11, 40
+    g, l, f, o = _r(B, G), _r(B, Vp, seed=1), _r(B, seed=2), _r(B, Vp, seed=3)
+    gen = torch.Generator().manual_seed(3)
+    rb = lambda *s: (torch.rand(*s, generator=gen) > 0.4).cuda()
+    gm, gv, vn, vo = rb(B, G), rb(B, G), rb(B, Vp), rb(B, Vp)
+    src = torch.randint(-2, Vp, (B, G), generator=gen).int().cuda()
+    bw = (torch.rand(B, Vp, generator=gen) > 0.7).to(torch.uint8).cuda()
+    a = K.nav_logits(g, l, f, gm, gv, vn, src, bw)
+    b4 = K.nav_logits(g, l, f, gm, gv, vn, src, bw, o, vo)
+    assert all(torch.equal(x, y) for x, y in zip(a, b4[:3]))
+    assert torch.equal(b4[3], o.masked_fill(~vo, -float('inf')))
