@@ -30,7 +30,7 @@ MAX_TRANSPOSES = 24
 class GemmProblem(C.Structure):
     _fields_ = [('A', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p),
                 ('C', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
-                ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32),
+                ('lda', C.c_int32), ('ldw', C.c_int32), ('ldr', C.c_int32), ('ldc', C.c_int32), ('reserved0_', C.c_int32),
                 ('a_stats', C.c_void_p), ('a_c1', C.c_void_p), ('r_stats', C.c_void_p), ('r_gamma', C.c_void_p),
                 ('r_beta', C.c_void_p), ('stats_out', C.c_void_p), ('a_np', C.c_int32), ('r_np', C.c_int32),
                 ('ln_eps', C.c_float), ('trans', C.c_int32), ('a_colsum', C.c_void_p), ('c_pre', C.c_void_p), ('ldcp', C.c_int32), ('res_act', C.c_int32)]

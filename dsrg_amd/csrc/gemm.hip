@@ -126,11 +126,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   // for any grid size), and logical ids walk the tile grid in super-rows of GM M-tiles with N fastest-but-one:
   // the ~32 tiles an XCD runs at a time then form a compact GM x (32/GM) patch that shares A and W panels in L2.
   int bid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
-    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-  }
+#define DSRG_REMAP_BID()                                                                                   \
+  do {                                                                                                     \
+    const int nwg = gridDim.x, orig = blockIdx.x;                                                          \
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;                                                 \
+    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);                     \
+  } while (0)
   // The launch record comes in through scalar loads from the kernarg segment, 300-500+ cycles each when they miss.  Left to
   // the compiler they are sunk to their first uses: 7 dependent load -> wait round trips before the first DMA could be
   // issued (in-kernel stamps: 2500-5300 cycles from kernel entry to the first stage, a third of a 64x64 tile's lifetime).
@@ -141,12 +142,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #define DSRG_PIN_PROBLEM(P_)                                                                                                        \
   do {                                                                                                                              \
     asm volatile("" ::"s"(P_.A), "s"(P_.W), "s"(P_.bias), "s"(P_.residual), "s"(P_.C), "s"(P_.M), "s"(P_.N), "s"(P_.K), "s"(P_.lda), \
-                 "s"(P_.ldw), "s"(P_.ldr), "s"(P_.ldc), "s"(P_.c_pre), "s"(P_.ldcp), "s"(P_.res_act), "s"(P_.a_colsum));              \
-    if constexpr (FUSE == FUSE_A) asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.a_np), "s"(P_.ln_eps));                   \
+                 "s"(P_.ldw), "s"(P_.ldr), "s"(P_.ldc), "s"(P_.c_pre), "s"(P_.ldcp), "s"(P_.res_act), "s"(P_.a_colsum), "s"(P_.reserved0_)); \
+    /* (ln_eps is NOT pinned: the allocator gave it a register of the wide load in flight above it, which split the entry   \
+       batch into two dependent round trips, ~1000 cycles of prologue in the round-3 stamps; it is read in the epilogue) */    \
+    if constexpr (FUSE == FUSE_A) asm volatile("" ::"s"(P_.a_stats), "s"(P_.a_c1), "s"(P_.a_np));                                   \
     if constexpr (FUSE == FUSE_RS)                                                                                                  \
-      asm volatile("" ::"s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out), "s"(P_.r_np), "s"(P_.ln_eps));          \
+      asm volatile("" ::"s"(P_.r_stats), "s"(P_.r_gamma), "s"(P_.r_beta), "s"(P_.stats_out), "s"(P_.r_np));                          \
   } while (0)
+  // ... together with the grid size (gridDim.x is a scalar load from the kernarg segment too: with the block-id remap first,
+  // every launch paid that round trip alone before the batch was issued) and the tile starts of the problem search
+  {
+    const int nwg_ = gridDim.x;
+    asm volatile("" ::"s"(nwg_), "s"(args.tile_start[1]), "s"(args.tile_start[2]), "s"(args.tile_start[3]), "s"(args.tile_start[4]),
+                 "s"(args.tile_start[5]), "s"(args.tile_start[6]), "s"(args.tile_start[7]), "s"(args.tile_start[8]), "s"(args.pw[0]));
+    // (every dword of the wide scalar loads is named here or in DSRG_PIN_PROBLEM - reserved0_ and tile_start[8] included:
+    // the allocator otherwise hands a dead dword's register to a later load, which then has to wait for the wide one and
+    // splits the batch into two dependent round trips)
+  }
   DSRG_PIN_PROBLEM(P);                      // (in front of the search: its loads go out with the tile starts')
+  DSRG_REMAP_BID();
+#undef DSRG_REMAP_BID
   int g = 0, tstart = 0, PW = args.pw[0];
 #pragma unroll
   for (int i = 1; i < DSRG_MAX_GROUPS; ++i)
@@ -209,53 +224,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
       for (int e = 0; e < CW; ++e)
         if (n + e < N) bv[e] = bias[n + e];
-    }
-  }
-
-  // ---- FUSE: this thread's share of the LayerNorm partials of its tile's rows (row = tid % BM, every TG-th partial from
-  // tid / BM on), issued here with everything else that can hide behind the first stage (block-major table: a wave's 64
-  // rows of one block are 512 contiguous bytes); they are summed after the K loop.
-  constexpr int TG = THREADS / BM > 0 ? THREADS / BM : 1;     // threads per tile row (4 at BM = 64, 2 at BM = 128)
-  constexpr int SP = 16 / TG;                                 // partial loads per thread: a_np, r_np <= 16
-  float2 pl[FUSE ? SP : 1];
-  const float* __restrict__ stp = nullptr;
-  int snp = 1;
-  if constexpr (FUSE == FUSE_A) { stp = P.a_stats; snp = P.a_np; }
-  if constexpr (FUSE == FUSE_RS) { stp = P.r_stats; snp = P.r_np; }
-  if constexpr (FUSE != 0) {
-    static_assert(THREADS % BM == 0 && TG * SP == 16, "the fused epilogue sums 16 / TG partials per thread");
-    const int srow = min(m0 + (tid % BM), M - 1), sg = tid / BM;
-#pragma unroll
-    for (int j = 0; j < SP; ++j) pl[j] = make_float2(0.f, 0.f);
-    if (stp) {
-      const float2* ps_ = reinterpret_cast<const float2*>(stp) + srow;
-#pragma unroll
-      for (int j = 0; j < SP; ++j) pl[j] = ps_[(size_t)min(sg + TG * j, snp - 1) * M];
-    }
-  }
-  // ... and the per-column vectors of this thread's CW output columns (row sums of the folded weight; residual gamma / beta)
-  float c1v[FUSE == FUSE_A ? CW : 1], rgv[FUSE == FUSE_RS ? CW : 1], rbv[FUSE == FUSE_RS ? CW : 1];
-  if constexpr (FUSE == FUSE_A) {
-#pragma unroll
-    for (int e = 0; e < CW; ++e) c1v[e] = 0.f;
-    if (stp && n + CW - 1 < N) {
-#pragma unroll
-      for (int h = 0; h < CW / 4; ++h) {
-        const float4 t4 = *reinterpret_cast<const float4*>(P.a_c1 + n + 4 * h);
-        c1v[4 * h] = t4.x; c1v[4 * h + 1] = t4.y; c1v[4 * h + 2] = t4.z; c1v[4 * h + 3] = t4.w;
-      }
-    }
-  }
-  if constexpr (FUSE == FUSE_RS) {
-#pragma unroll
-    for (int e = 0; e < CW; ++e) { rgv[e] = 1.f; rbv[e] = 0.f; }
-    if (stp && n + CW - 1 < N) {
-#pragma unroll
-      for (int h = 0; h < CW / 4; ++h) {
-        const float4 g4 = *reinterpret_cast<const float4*>(P.r_gamma + n + 4 * h), b4 = *reinterpret_cast<const float4*>(P.r_beta + n + 4 * h);
-        rgv[4 * h] = g4.x; rgv[4 * h + 1] = g4.y; rgv[4 * h + 2] = g4.z; rgv[4 * h + 3] = g4.w;
-        rbv[4 * h] = b4.x; rbv[4 * h + 1] = b4.y; rbv[4 * h + 2] = b4.z; rbv[4 * h + 3] = b4.w;
-      }
     }
   }
 
@@ -451,6 +419,55 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
   uint4 fa0[MT], fw0[NT], fa1[MT], fw1[NT];
   land(0);
   GEMM_STAMP(1);
+  // ---- FUSE: this thread's share of the LayerNorm partials of its tile's rows (row = tid % BM, every TG-th partial from
+  // tid / BM on), issued once the first stage has LANDED (block-major table: a wave's 64 rows of one block are 512 contiguous bytes) and
+  // summed after the K loop.  Completion is counted in issue order: in front of the ring's first DMAs these loads held the
+  // first stage back by their own misses, right behind them they made land(0) wait for the second stage as well; here they
+  // are older than every refill, so the counted waits of the K loop cover them (stricter by a few pieces, never wrong).
+  constexpr int TG = THREADS / BM > 0 ? THREADS / BM : 1;     // threads per tile row (4 at BM = 64, 2 at BM = 128)
+  constexpr int SP = 16 / TG;                                 // partial loads per thread: a_np, r_np <= 16
+  float2 pl[FUSE ? SP : 1];
+  const float* __restrict__ stp = nullptr;
+  int snp = 1;
+  if constexpr (FUSE == FUSE_A) { stp = P.a_stats; snp = P.a_np; }
+  if constexpr (FUSE == FUSE_RS) { stp = P.r_stats; snp = P.r_np; }
+  if constexpr (FUSE != 0) {
+    static_assert(THREADS % BM == 0 && TG * SP == 16, "the fused epilogue sums 16 / TG partials per thread");
+    const int srow = min(m0 + (tid % BM), M - 1), sg = tid / BM;
+#pragma unroll
+    for (int j = 0; j < SP; ++j) pl[j] = make_float2(0.f, 0.f);
+    if (stp) {
+      const float2* ps_ = reinterpret_cast<const float2*>(stp) + srow;
+#pragma unroll
+      for (int j = 0; j < SP; ++j) pl[j] = ps_[(size_t)min(sg + TG * j, snp - 1) * M];
+    }
+  }
+  // ... and the per-column vectors of this thread's CW output columns (row sums of the folded weight; residual gamma / beta)
+  float c1v[FUSE == FUSE_A ? CW : 1], rgv[FUSE == FUSE_RS ? CW : 1], rbv[FUSE == FUSE_RS ? CW : 1];
+  if constexpr (FUSE == FUSE_A) {
+#pragma unroll
+    for (int e = 0; e < CW; ++e) c1v[e] = 0.f;
+    if (stp && n + CW - 1 < N) {
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        const float4 t4 = *reinterpret_cast<const float4*>(P.a_c1 + n + 4 * h);
+        c1v[4 * h] = t4.x; c1v[4 * h + 1] = t4.y; c1v[4 * h + 2] = t4.z; c1v[4 * h + 3] = t4.w;
+      }
+    }
+  }
+  if constexpr (FUSE == FUSE_RS) {
+#pragma unroll
+    for (int e = 0; e < CW; ++e) { rgv[e] = 1.f; rbv[e] = 0.f; }
+    if (stp && n + CW - 1 < N) {
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        const float4 g4 = *reinterpret_cast<const float4*>(P.r_gamma + n + 4 * h), b4 = *reinterpret_cast<const float4*>(P.r_beta + n + 4 * h);
+        rgv[4 * h] = g4.x; rgv[4 * h + 1] = g4.y; rgv[4 * h + 2] = g4.z; rgv[4 * h + 3] = g4.w;
+        rbv[4 * h] = b4.x; rbv[4 * h + 1] = b4.y; rbv[4 * h + 2] = b4.z; rbv[4 * h + 3] = b4.w;
+      }
+    }
+  }
+
 #if DSRG_ABLATE != 1
   if (D < nk) {
 #pragma unroll
@@ -548,6 +565,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     static_assert(NG % TG == 0, "a thread owns NG / TG groups");
     constexpr int GPT = NG / TG;                   // groups per thread (1 at BM = 64, 2 at BM = 128)
     const int sg = tid / BM;
+    // The partials loaded in the prologue become visible to the optimiser only HERE: left alone it hoisted the first
+    // addition up to the loads and waited for them (s_waitcnt vmcnt(3) in front of the first DMA: a whole cold-miss latency,
+    // 1200-2000 cycles of prologue in the round-3 stamps).
+#pragma unroll
+    for (int j = 0; j < SP; ++j) asm volatile("" : "+v"(pl[j].x), "+v"(pl[j].y));
     float2 sa[GPT];
 #pragma unroll
     for (int gi = 0; gi < GPT; ++gi) sa[gi] = make_float2(0.f, 0.f);
@@ -558,6 +580,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
     for (int gi = 0; gi < GPT; ++gi) lnpart[(sg + TG * gi) * BM + (tid % BM)] = sa[gi];
   }
+  float2* __restrict__ sto = nullptr;
+  if constexpr (FUSE == FUSE_RS) sto = reinterpret_cast<float2*>(P.stats_out);
   auto rows_out = [&](auto act_tag, auto ract_tag) {
   constexpr int ACT = decltype(act_tag)::value, RACT = decltype(ract_tag)::value;   // -1: run-time (see apply_act_c)
 #pragma unroll
@@ -667,11 +691,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
               const float4 rr = raw4(raw);
               rv[0] = rr.x; rv[1] = rr.y; rv[2] = rr.z; rv[3] = rr.w;
             }
-            if constexpr (FUSE == FUSE_RS) {
-              if (stp) {
+            if constexpr (FUSE == FUSE_RS) {       // no r_stats: ms = (0, 1), gamma = 1, beta = 0 -> the residual itself, exactly (no branch)
 #pragma unroll
-                for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - ms.x) * ms.y * rgv[e] + rbv[e];
-              }
+              for (int e = 0; e < CW; ++e) rv[e] = (rv[e] - ms.x) * ms.y * rgv[e] + rbv[e];
             }
             if (RACT > 0 || (RACT < 0 && res_act > 0)) {
 #pragma unroll
@@ -682,15 +704,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
             }
           }
           if constexpr (FUSE == FUSE_RS) {
-            if (P.stats_out) {        // partial (sum, sum of squares) of this row over each 64-column block, from the fp32 values
-              static_assert(FUSE != FUSE_RS || BN % 64 == 0, "statistics are kept per 64-column block");
-              constexpr int L64 = 64 / CW;          // consecutive lanes that hold one row's 64 columns (8 or 16): DPP, not LDS shuffles
-              float s1 = 0.f, s2 = 0.f;
+            // partial (sum, sum of squares) of this row over each 64-column block, from the fp32 values; always computed
+            // (straight-line code), stored by the block's first lane when the problem asks for it
+            static_assert(FUSE != FUSE_RS || BN % 64 == 0, "statistics are kept per 64-column block");
+            constexpr int L64 = 64 / CW;          // consecutive lanes that hold one row's 64 columns (8 or 16): DPP, not LDS shuffles
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-              for (int e = 0; e < CW; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-              s1 = dpp_group_sum<L64>(s1); s2 = dpp_group_sum<L64>(s2);
-              if ((oc & (L64 - 1)) == 0) reinterpret_cast<float2*>(P.stats_out)[(size_t)(n >> 6) * M + m] = make_float2(s1, s2);
-            }
+            for (int e = 0; e < CW; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+            s1 = dpp_group_sum<L64>(s1); s2 = dpp_group_sum<L64>(s2);
+            if (sto && (oc & (L64 - 1)) == 0) sto[(size_t)(n >> 6) * M + m] = make_float2(s1, s2);
           }
           if constexpr (CW == 8) {
             uint4 u;

@@ -183,7 +183,7 @@ class GlocalTextPathNavCMT(nn.Module):
         # inference: the LayerNorms inside the x-layers folded into the neighbouring GEMM epilogues (_x_layers_fused_gen).
         # Off by default since r02t: with the specialised GEMM epilogue the plain kernels gained more than the FUSE ones
         # (c2 step 1.180 ms unfused vs 1.197 fused), and only the plain kernels have the wide tiles (1.162)
-        self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '0') == '1'
+        self.fuse_ln = os.environ.get('DSRG_FUSE_LN', '1') == '1'
         # two-stream schedule: branches captured launch by launch in turn instead of one whole branch after the other
         # (measured: no difference in the replayed graph, 1.1976 vs 1.1995 ms; off)
         self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
@@ -457,14 +457,19 @@ class GlocalTextPathNavCMT(nn.Module):
             valid = K.KeyLens(lens.reshape(B, V).contiguous(), O)      # the attention kernel forms the mask from the lengths
         else:
             valid = (_arange(O, fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
-        for i in range(2):
-            e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
+        if self._fuse_ok(d):
+            e = self._bert_layers_fused(W, ['objenc.%d' % i for i in range(2)], e, d // 64, valid, MASK_PLUS1)
+        else:
+            for i in range(2):
+                e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
         return e.reshape(B * V * O, d), O
 
     def _pano_encoder(self, W, x, masks):
         """2 pre-norm layers over packed-in_proj MHA with -inf key padding (transformer.py:170-182)."""
         cfg = self.config
         H, nh, p = cfg.hidden_size, cfg.num_attention_heads, cfg.hidden_dropout_prob
+        if self._fuse_ok(H):
+            return self._pano_encoder_fused(W, x, masks)
         for i in range(cfg.num_pano_layers):
             k = 'pano.%d' % i
             y = Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5)
@@ -627,6 +632,66 @@ class GlocalTextPathNavCMT(nn.Module):
             wf = (w.float() * g[None]).to(w.dtype).contiguous()
             F[k] = (wf, wf.float().sum(1).contiguous(), (W[lin_key + '.b'] + w.float() @ b).contiguous())
         return F[k]
+
+    # ---- LayerNorm folded into the neighbouring GEMM epilogues (inference; dsrg_gemm_problem_t stats_out / a_stats / r_stats)
+    def _fuse_ok(self, H):
+        return self.fuse_ln and not torch.is_grad_enabled() and not self.training and H % 64 == 0 and H <= 1024
+
+    def _fz_proj(self, W, t, st, lnk, lin, eps, act=ACT_NONE):
+        """act(LN_lnk(t) W[lin]^T + b) with t un-normalised and st its partial statistics (st None: t is materialised)"""
+        if st is None:
+            return K.gemm([(t, W[lin + '.w'], W[lin + '.b'], None)], act)[0]
+        wf, c1, bf_ = self._folded(W, lin, lnk)
+        return K.gemm([(t, wf, bf_, None)], act, fuse=[{'a_stats': (st, c1), 'eps': eps}])[0]
+
+    def _fz_dense_res(self, W, h, lin, res, res_st, res_lnk, eps, want_stats=True, out_f32=False):
+        """y = h W[lin]^T + b + (LN_res_lnk(res) if res_st is given else res) -> (y, partial statistics of y | None)"""
+        d = {'eps': eps}
+        if res_st is not None:
+            d['r_stats'] = (res_st, W[res_lnk + '.g'], W[res_lnk + '.b'])
+        st = None
+        if want_stats:
+            N = W[lin + '.w'].shape[0]
+            st = d['stats_out'] = torch.empty(N // 64, h.numel() // h.shape[-1], 2, device=h.device, dtype=torch.float32)
+        if len(d) == 1:
+            return K.gemm([(h, W[lin + '.w'], W[lin + '.b'], res)], ACT_NONE, out_f32)[0], None
+        return K.gemm([(h, W[lin + '.w'], W[lin + '.b'], res)], ACT_NONE, out_f32, fuse=[d])[0], st
+
+    def _bert_layers_fused(self, W, keys, x, nh, kmask, mode):
+        """Post-LN BERT layers (vilmodel.py:219-232; the ASV object self-encoder) without their LayerNorm launches: every
+        sub-block leaves its un-normalised sum and the partial statistics, the projections that read it carry the correction
+        in their epilogue; one LayerNorm launch at the end materialises the output."""
+        eps = self.config.layer_norm_eps
+        H = x.shape[-1]
+        t, st, lnk = x.contiguous(), None, None
+        for key in keys:
+            qkv = self._fz_proj(W, t, st, lnk, key + '.qkv', eps)
+            a = K.attention_grouped([(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, None)], nh, mode)[0]
+            t, st = self._fz_dense_res(W, a, key + '.ao', t, st, lnk, eps)
+            lnk = key + '.aln'
+            h = self._fz_proj(W, t, st, lnk, key + '.ff1', eps, ACT_GELU)
+            t, st = self._fz_dense_res(W, h, key + '.ff2', t, st, lnk, eps)
+            lnk = key + '.fln'
+        return K.layernorm_grouped([(t, W[lnk + '.g'], W[lnk + '.b'], None)], eps, self.compute_dtype)[0]
+
+    def _pano_encoder_fused(self, W, x, masks):
+        """The pre-norm panorama encoder (transformer.py:170-182) with norm1 / norm2 folded into the projections that read
+        them: the residual stream x stays un-normalised anyway; out_proj / linear2 (+ residual) also write its partial
+        statistics.  Only the first norm1 (its input comes from the embedding kernel) is a launch."""
+        cfg = self.config
+        H, nh = cfg.hidden_size, cfg.num_attention_heads
+        st = None
+        for i in range(cfg.num_pano_layers):
+            k = 'pano.%d' % i
+            if st is None:
+                qkv = K.gemm([(Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5), W[k + '.qkv.w'], W[k + '.qkv.b'], None)])[0]
+            else:
+                qkv = self._fz_proj(W, x, st, k + '.n1', k + '.qkv', 1e-5)
+            a = Fn.attention_packed(qkv, nh, None, masks, MASK_NEGINF)
+            x, st = self._fz_dense_res(W, a, k + '.ao', x, None, None, 1e-5)
+            h = self._fz_proj(W, x, st, k + '.n2', k + '.ff1', 1e-5, ACT_GELU)
+            x, st = self._fz_dense_res(W, h, k + '.ff2', x, None, None, 1e-5, want_stats=i + 1 < cfg.num_pano_layers)
+        return x
 
     def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs, final_aux=None):
         """(generator: yields after every launch, returns the result - see _x_layers_gen)

@@ -46,6 +46,7 @@ typedef struct {
   const void* A; const void* W; const float* bias; const void* residual; void* C;
   int32_t M, N, K;
   int32_t lda, ldw, ldr, ldc;
+  int32_t reserved0_;     /* (the alignment hole in front of the next pointer, named: set to 0) */
   /* Optional LayerNorm fusion (all NULL / 0 = plain GEMM).  A post-LN block  x1 = LN(y),  y = dense(..) + residual
    * (BertSelfOutput / BertOutput, FT/vilmodel.py:173-177, 213-217) followed by projections of x1 needs no standalone
    * LayerNorm launch and no fp32 copy of y:
