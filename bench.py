@@ -7,10 +7,11 @@ One step = one 'panorama' + one 'navigation' call on a batch of 64 episodes (syn
 inside the timed region, as a rollout would.  N>1: one process per GPU (torchrun), independent replicas of 64
 episodes each (weak scaling, no data-path collective); value = N*64*K / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1|c4] [--dtype bf16|fp32] [--eager]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1|c4|ft] [--dtype bf16|fp32] [--eager]
 
 --config c4 is BASELINE config[3]: one R2R pre-training optimisation step (MLM / MRC / SAP round-robin, forward +
 backward + gradient clipping + AdamW, 24 trajectories per GPU, DDP gradient all-reduce over RCCL when N>1).
+--config ft is one R2R fine-tuning optimisation step (two rollouts, one backward, clip 40, AdamW; agent_base.py:180-216).
 """
 import argparse
 import json
@@ -201,8 +202,8 @@ def gemm_roofline(step_fn, dtype, cfg='c2'):
     (bm, bn, nst), odt, fused, trans = dom
     peak = MFMA_PEAK_BF16 if dtype == torch.bfloat16 else MFMA_PEAK_F32
     tot_f = sum(v['flops'] for v in by_tile.values()); tot_t = sum(v['time'] for v in by_tile.values())
-    sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d, %s, %d, 2, %d>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
-                                                                  'float' if odt == 0 else 'unsigned short', bm, bn, nst, 'true' if fused else 'false',
+    sig = 'gemm_nt_kernel<%s, %s, %d, %d, %d, %d, %d, 2, %d>' % ('unsigned short' if dtype == torch.bfloat16 else 'float',
+                                                                  'float' if odt == 0 else 'unsigned short', bm, bn, nst, int(fused),
                                                                   4 if bm == 256 else 2, trans)
     traffic, src = pmc_traffic(sig, d['grids'], cfg)
     prof_us, prof_src = profile_avg_us(sig, cfg)
@@ -213,12 +214,12 @@ def gemm_roofline(step_fn, dtype, cfg='c2'):
             'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE)',
             'traffic_source': src, 'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
             'algorithmic_flops_per_launch': fpl,
-            'kernel': sig, 'ln_fused_epilogue': fused, 'operand_form': {0: 'NT', 1: 'TN (A stored [K,M])', 2: 'NN (dgrad)', 3: 'TN (wgrad)'}[trans], 'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
+            'kernel': sig, 'ln_fused_epilogue': {0: 'none', 1: 'a_stats (consumer)', 2: 'r_stats / stats_out (producer)'}[int(fused)], 'operand_form': {0: 'NT', 1: 'TN (A stored [K,M])', 2: 'NN (dgrad)', 3: 'TN (wgrad)'}[trans], 'launches_per_step': d['launches'], 'avg_launch_us': d['time'] / d['launches'] * 1e6,
             'avg_launch_us_isolated': d['hot'] / d['launches'] * 1e6,
             'timing': 'HIP events around a graph of the variant\'s launches in step order, operands cold (as in the step)',
             'all_gemm_tflops': tot_f / tot_t / 1e12, 'all_gemm_launches_per_step': len(trace),
             'all_gemm_us_per_step': tot_t * 1e6,
-            'variants': {'%dx%dx%d/%s%s%s' % (k[0] + ('f32' if k[1] == 0 else 'bf16', '/ln-fused' if k[2] else '', {0: '', 1: '/tn', 2: '/nn-dgrad', 3: '/tn-wgrad'}[k[3]])): {'launches': v['launches'], 'us': v['time'] * 1e6, 'tflops': v['flops'] / v['time'] / 1e12}
+            'variants': {'%dx%dx%d/%s%s%s' % (k[0] + ('f32' if k[1] == 0 else 'bf16', {0: '', 1: '/ln-a_stats', 2: '/ln-r_stats+stats_out'}[int(k[2])], {0: '', 1: '/tn', 2: '/nn-dgrad', 3: '/tn-wgrad'}[k[3]])): {'launches': v['launches'], 'us': v['time'] * 1e6, 'tflops': v['flops'] / v['time'] / 1e12}
                          for k, v in by_tile.items()}}
 
 
@@ -264,7 +265,10 @@ def pretrain_main(a, dtype, dev, rank, world):
         opt.step()
         last[task] = loss.detach()
 
-    # main thread + autograd thread on one core (before the first backward creates the engine thread): D.pin_step_threads
+    # main thread + autograd thread on one core (before the first backward creates the engine thread): D.pin_step_threads.
+    # The intra-op pool of the CPU baseline leg is created FIRST: threads born under the pin would inherit the one-core mask.
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.mm(torch.ones(256, 256), torch.ones(256, 256))
     prev_mask = None if a.no_pin else D.pin_step_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     for i in range(a.warmup):
         step(i)
@@ -335,6 +339,191 @@ def pretrain_cpu_baseline(cfg, sd, budget_s=25.0):
     dt = time.perf_counter() - t0
     return {'value': Bc * it / dt, 'unit': 'trajectories/s', 'cores': cores, 'kind': 'port',
             'sample': '%d forward+backward steps of %d trajectories (no optimiser step, fp32, %d threads), %.1f s' % (it, Bc, cores, dt)}
+
+
+
+FT_B, FT_T = 8, 7          # episodes per GPU (the reference fine-tunes REVERIE with bs 8, R2R with 4: scripts/run_*.sh); steps per rollout
+
+
+class _RolloutLoss(torch.nn.Module):
+    """One fine-tuning iteration's loss (finetune_src/r2r/agent_base.py:180-216, agent.py:396-578): two rollouts - teacher
+    forcing weighted 0.2, sampling weighted 1.0 - each language -> T x (panorama -> navigation) with the RMF memory and the
+    panorama embeddings carried inside the autograd graph, CrossEntropy(sum, ignore_index=-100) / B on the fused logits of
+    every step.  One nn.Module so that DDP sees ONE forward per backward."""
+
+    def __init__(self, model, feat_dropout=0.4):
+        super().__init__()
+        self.model, self.feat_dropout = model, feat_dropout
+
+    def rollout(self, lb, pbs, nbs, targets):
+        from dsrg_amd import functional as Fn
+        m = self.model
+        txt = m('language', lb)
+        B = txt.shape[0]
+        cls, loss = None, 0.0
+        for pb, nb0, tg in zip(pbs, nbs, targets):
+            pb = dict(pb)
+            pb['view_img_fts'] = torch.nn.functional.dropout(pb['view_img_fts'], self.feat_dropout, self.training)   # VLNBert.drop_env (model.py:29)
+            pe, pm, pf = m('panorama', pb)
+            mem = torch.zeros(B, pe.shape[-1], device=pe.device, dtype=pe.dtype) if cls is None else cls
+            nb = dict(nb0)
+            nb['vp_img_embeds'] = torch.cat([torch.zeros_like(mem)[:, None], mem[:, None], pe], 1)                    # agent.py:231-237
+            g = nb0['gmap_img_embeds']
+            nb['gmap_img_embeds'] = torch.cat([g[:, :1], mem[:, None], pf[:, None], g[:, 3:]], 1)                     # agent.py:185-188, 443-447
+            nb['txt_embeds'], nb['txt_masks'] = txt, lb['txt_masks']
+            o = m('navigation', nb)
+            cls = o['cls_embeds']
+            loss = loss + Fn.cross_entropy_rows(o['fused_logits'], tg).sum() / B                                      # agent.py:502, agent_base.py:150
+        return loss
+
+    def forward(self, lb, pbs, nbs, targets):
+        return 0.2 * self.rollout(lb, pbs, nbs, targets[0]) + 1.0 * self.rollout(lb, pbs, nbs, targets[1])
+
+
+def finetune_batches(B, nsteps, L, G, dev, dtype, model, seed=300):
+    """Synthetic rollout inputs, resident on the device: instruction, T panoramas, T graph-map states (fusion indices
+    precomputed on the host as the device-resident graph map does), and teacher targets = a valid node."""
+    from dsrg_amd import synth
+    lb = T(synth.language_batch(B, L, seed), dev)
+    pbs, nbs, tg = [], [], [[], []]
+    for t in range(nsteps):
+        pbn = synth.panorama_batch(B, 36, 3, seed + 10 * t)
+        nbn = synth.navigation_batch(B, G, 38, seed + 10 * t, ncand=pbn['ncand'], nav_types=pbn['nav_types'])
+        src, bw = model.fusion_indices(nbn['gmap_vpids'], nbn['gmap_visited_masks'], nbn['vp_cand_vpids'], G, 38, 2)
+        pb, nb = T(pbn, dev), T(nbn, dev)
+        nb['gmap_src'], nb['bw_mask'] = torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev)
+        nb['gmap_img_embeds'] = nb['gmap_img_embeds'].to(dtype)
+        ok = nbn['gmap_masks'] & ~nbn['gmap_visited_masks']             # nodes whose fused logit is finite
+        ok[:, 0] = True
+        for r in range(2):
+            rng = np.random.RandomState(seed + 97 * t + r)
+            pick = np.array([rng.choice(np.nonzero(ok[i])[0]) for i in range(B)], np.int64)
+            pick[rng.rand(B) < 0.15] = -100                              # ended episodes are ignored by the loss (agent.py:497-500)
+            tg[r].append(torch.from_numpy(pick).to(dev))
+        pbs.append(pb); nbs.append(nb)
+    return lb, pbs, nbs, tg
+
+
+def finetune_main(a, dtype, dev, rank, world):
+    """`--config ft`: one fine-tuning optimisation step of the R2R agent's policy network = two rollouts (forward with
+    autograd), ONE backward, clip_grad_norm_(40), AdamW - finetune_src/r2r/agent_base.py:180-216; dropout as in training."""
+    from dsrg_amd import synth, distributed as D
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.vilmodel import GlocalTextPathNavCMT
+    B, T, L, G = a.ft_batch, FT_T, 80, 20
+    cfg = DSRGConfig()
+    model = GlocalTextPathNavCMT(cfg, compute_dtype=dtype)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes).items()}
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    step_mod = _RolloutLoss(model).train()
+    ddp = D.wrap_model(step_mod, dev, bf16_grads=(dtype == torch.bfloat16))
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-5, fused=True)
+    lb, pbs, nbs, tg = finetune_batches(B, T, L, G, dev, dtype, model, 300 + rank)
+    last = {}
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = ddp(lb, pbs, nbs, tg)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 40.0)
+        opt.step()
+        last['loss'] = loss.detach()
+
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    torch.mm(torch.ones(256, 256), torch.ones(256, 256))       # the intra-op pool exists before the pin below: its threads keep the full mask
+    prev_mask = None if a.no_pin else D.pin_step_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if prev_mask:
+        os.sched_setaffinity(0, prev_mask)
+    evidence = None
+    if world > 1:
+        dt, evidence = rank_evidence(dt, dev, world)
+    assert torch.isfinite(last['loss']), 'non-finite fine-tuning loss'
+    if rank == 0:
+        out = {'metric': 'R2R fine-tuning optimisation steps (2 rollouts of %d nav-steps, 1 backward): episodes/s' % T,
+               'value': world * B * a.steps / dt, 'unit': 'episodes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+               'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
+               'data': 'synthetic',
+               'config': {'workload': 'R2R fine-tuning step (finetune_src/r2r/agent_base.py:180-216): teacher + sample rollout, CE(sum)/B, '
+                                      'one backward, clip 40, AdamW, %s' % a.dtype, 'name': 'ft', 'episodes_per_gpu': B,
+                          'nav_steps_per_rollout': T, 'txt_len': L, 'graph_nodes': G, 'dropout': cfg.hidden_dropout_prob, 'feat_dropout': 0.4,
+                          'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else
+                                          'DDP x%d (rehearsal: gloo, gradient buckets staged through host memory)' % world) if world > 1 else 'single GPU'},
+               'nav_steps_per_s': world * B * 2 * T * a.steps / dt, 'final_loss': float(last['loss'])}
+        if evidence:
+            out['ranks_seen'], out['backend'] = evidence['ranks_seen'], evidence['backend']
+            out['per_rank_ms'] = [t / a.steps * 1e3 for t in evidence['per_rank_s']]
+        if not a.no_roofline:
+            def one_step():
+                opt.zero_grad(set_to_none=True)
+                step_mod(lb, pbs, nbs, tg).backward()
+            out['roofline'] = gemm_roofline(one_step, dtype, 'ft')
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = finetune_cpu_baseline(cfg, sd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def finetune_cpu_baseline(cfg, sd, budget_s=25.0):
+    """CPU oracle (oracle/dsrg_oracle.py, autograd on) on a bounded sample of the same step: 2 episodes, the same two
+    rollouts of FT_T nav-steps + backward (no optimiser step)."""
+    from dsrg_amd import synth
+    from oracle import dsrg_oracle
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sdg = {k: v.clone().float().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    Bc, Tc = 2, FT_T
+    from dsrg_amd.vilmodel import GlocalTextPathNavCMT
+    lb, pbs, nbs, tg = finetune_batches(Bc, Tc, 80, 20, 'cpu', torch.float32, GlocalTextPathNavCMT, 300)
+
+    class _O:            # the oracle behind the model's call signature
+        training = False
+
+        def __call__(self, mode, b):
+            return dsrg_oracle.forward(sdg, cfg, mode, b, grad=True)
+    import types
+    step_mod = _RolloutLoss.__new__(_RolloutLoss)
+    torch.nn.Module.__init__(step_mod)
+    object.__setattr__(step_mod, 'model', _O())
+    step_mod.feat_dropout = 0.0
+
+    def ce(lg, t):      # the reference's criterion (agent_base.py:150)
+        return torch.nn.functional.cross_entropy(lg, t, ignore_index=-100, reduction='none')
+    import dsrg_amd.functional as Fn
+    real = Fn.cross_entropy_rows
+    Fn.cross_entropy_rows = ce
+    try:
+        t0, it = time.perf_counter(), 0
+        while it < 2 or (time.perf_counter() - t0 < budget_s and it < 12):
+            step_mod(lb, pbs, nbs, tg).backward()
+            for v in sdg.values():
+                v.grad = None
+            it += 1
+        dtc = time.perf_counter() - t0
+    finally:
+        Fn.cross_entropy_rows = real
+    return {'value': Bc * it / dtc, 'unit': 'episodes/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d forward+backward iterations of %d episodes x 2 rollouts x %d nav-steps (no optimiser step, fp32, %d threads), %.1f s'
+                      % (it, Bc, Tc, cores, dtc)}
 
 
 def rank_evidence(dt, dev, world):
@@ -438,7 +627,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--warmup', type=int, default=15)
-    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c4'])
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS) + ['c4', 'ft'])
+    ap.add_argument('--ft-batch', type=int, default=FT_B, help='ft: episodes per GPU')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--eager', action='store_true', help='launch kernels from Python each step instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -476,6 +666,8 @@ def main():
 
     if a.config == 'c4':
         return pretrain_main(a, dtype, dev, rank, world)
+    if a.config == 'ft':
+        return finetune_main(a, dtype, dev, rank, world)
     from dsrg_amd.runner import GraphedNavStep
     model, cfg, sd, lbs, pb, nb, dims = build(a.config, dtype, dev)
     reverie, B, L, G, O, No, Vp = dims
@@ -548,7 +740,7 @@ def main():
                         runner._body()
                 finally:
                     model.split_when_eager = False
-            out['roofline'] = gemm_roofline(one_step, dtype)
+            out['roofline'] = gemm_roofline(one_step, dtype, a.config)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, sd, lbs[0], pb, nb, dims)
         print(json.dumps(out), flush=True)

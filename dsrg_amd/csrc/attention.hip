@@ -1171,7 +1171,7 @@ extern "C" int dsrg_attention_bwd_strided(const void* Q, int64_t q_bs, int q_rs,
 // taken once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
 static __device__ __align__(256) float scratch[DSRG_ATTN_BWD_NOALLOC_MAX_ROWS];     // 4 MiB on every GPU the library runs on
 
-static int scratch_ptr(float** out) {
+static int scratch_ptr(float** out, hipStream_t capturing_on = nullptr, bool check_capture = false) {
   static std::mutex mu;
   static float* ptr[DSRG_MAX_DEVICES] = {};
   int dev = -1;
@@ -1181,6 +1181,13 @@ static int scratch_ptr(float** out) {
   }
   std::lock_guard<std::mutex> g(mu);
   if (!ptr[dev]) {
+    if (check_capture) {     // the symbol lookup below may load the code object: never inside a stream capture
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(capturing_on, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        dsrg_set_error("dsrg_attention_bwd_noalloc: first use on device %d inside a stream capture; call dsrg_init() on this device before capturing", dev);
+        return DSRG_EINVAL;
+      }
+    }
     float* p = nullptr;
     const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));     // this device's copy
     if (e != hipSuccess || !p) {
@@ -1205,9 +1212,16 @@ extern "C" int dsrg_attention_bwd_noalloc(const void* Q, int64_t q_bs, int q_rs,
              "dsrg_attention_bwd_noalloc: B*NH*Nq = %lld exceeds the static workspace of %d rows; use dsrg_attention_bwd with a caller workspace",
              (long long)B * NH * Nq, DSRG_ATTN_BWD_NOALLOC_MAX_ROWS);
   float* ws = nullptr;
-  const int rc = scratch_ptr(&ws);
+  const int rc = scratch_ptr(&ws, (hipStream_t)stream, true);
   if (rc != DSRG_OK) return rc;
   // nothing to clear: rows [0, B*NH*Nq) are all written by the dQ kernel before the dK/dV kernel (same stream) reads them
   return attention_bwd_impl(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, o_bs, o_rs, dO, do_bs, do_rs, lse, kmask, mask_mode, pair_dists,
                             sprel_w, sprel_b, dQ, dK, dV, ws, dsprel, B, NH, Nq, Nk, scale, p_drop, seed, dtype, stream);
+}
+
+// Per-device set-up that must not happen inside a stream capture (include/dsrg_hip.h): resolves the static workspace's
+// device address for the CURRENT device.  Idempotent, thread-safe.
+extern "C" int dsrg_init(void) {
+  float* ws = nullptr;
+  return scratch_ptr(&ws);
 }

@@ -350,6 +350,12 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     return dq, dk, dv, dsp
 
 
+def init():
+    """dsrg_init() for the current device: resolve the library's static workspace outside any stream capture (required
+    before attention_bwd_noalloc is captured into a HIP graph on this device)."""
+    _lib.check(_lib.load().dsrg_init(), 'dsrg_init')
+
+
 def attention_bwd_noalloc(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, sprel_b, dq, dk, dv, dsp=None, scale=0.125,
                           p_drop=0.0, seed=0):
     """dsrg_attention_bwd_noalloc: the caller passes every output (dq, dk, dv contiguous, dsp zeroed fp32 [2] or None); the

@@ -27,6 +27,12 @@ enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 
 
 int dsrg_abi_version(void);
 const char* dsrg_last_error(void);
+/* Per-device set-up, for the CURRENT device (hipSetDevice first): resolves the device address of the library's static
+ * workspace (dsrg_attention_bwd_noalloc).  Optional for eager callers - the first dsrg_attention_bwd_noalloc call on a
+ * device does it - but REQUIRED before that entry point is used under hipGraph / stream capture on the device: the lookup
+ * may load the code object and must not run inside a capture (the entry point then fails with DSRG_EINVAL and says so).
+ * Idempotent and thread-safe.  No counterpart in the reference. */
+int dsrg_init(void);
 
 /* ---- GEMM: C = act(A · Wᵀ + bias) [+ residual] ------------------------------------------------
  * Replaces every nn.Linear on the path (FT/vilmodel.py:111-113,169,195,209,338-340,555,577,622;

@@ -52,3 +52,37 @@ def test_noalloc_rejects_sizes_beyond_the_static_workspace():
     lse = torch.zeros(B, nh, Nq, device='cuda')
     with pytest.raises(_lib.DsrgHipError, match='exceeds the static workspace'):
         K.attention_bwd_noalloc(q, k, k, q, q, lse, nh, None, 0, None, None, None, torch.empty_like(q), torch.empty_like(k), torch.empty_like(k))
+
+
+def test_noalloc_under_graph_capture_after_init():
+    """The entry point is for callers that cannot allocate - HIP-graph capture among them: after dsrg_init() on the device
+    (the symbol lookup must not run inside a capture) a captured call replays to the bits of dsrg_attention_bwd, also on new
+    operand VALUES in the same buffers."""
+    from dsrg_amd import kernels as K
+    K.init()
+    B, nh, Nq, Nk, dtype = 6, 12, 38, 80, torch.bfloat16
+    g = torch.Generator(device='cpu').manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).cuda().to(dtype)
+    q, k, v, do = r(B, Nq, nh * 64), r(B, Nk, nh * 64), r(B, Nk, nh * 64), r(B, Nq, nh * 64)
+    kmask = (torch.rand(B, Nk, generator=g) > 0.3).cuda()
+    kmask[:, 0] = True
+    o, lse = K.attention(q, k, v, nh, kmask, 1, want_lse=True)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        K.attention_bwd_noalloc(q, k, v, o, do, lse, nh, kmask, 1, None, None, None, dq, dk, dv)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        K.attention_bwd_noalloc(q, k, v, o, do, lse, nh, kmask, 1, None, None, None, dq, dk, dv)
+    for rep in range(2):
+        if rep == 1:                                   # new values in the captured buffers
+            do.copy_(r(B, Nq, nh * 64))
+        for t in (dq, dk, dv):
+            t.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        want = K.attention_bwd(q, k, v, o, do, lse, nh, kmask, 1, None, None, None)
+        for a, b in zip((dq, dk, dv), want[:3]):
+            assert torch.equal(a, b)
