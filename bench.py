@@ -118,8 +118,10 @@ def pmc_traffic(kernel_sig, grids, cfg='c2'):
     import csv, glob
     here = os.path.dirname(os.path.abspath(__file__))
     tag = '' if cfg == 'c2' else cfg + '_'          # profiles/rNN_pmc_fetch.csv (c2) / rNN_c4_pmc_fetch.csv (pre-training step)
-    fetch = sorted(f for f in glob.glob(os.path.join(here, 'profiles', 'r*_%spmc_fetch.csv' % tag)) if cfg != 'c2' or '_c4_' not in f)
-    write = sorted(f for f in glob.glob(os.path.join(here, 'profiles', 'r*_%spmc_write.csv' % tag)) if cfg != 'c2' or '_c4_' not in f)
+    import re
+    pick = lambda kind: sorted(f for f in glob.glob(os.path.join(here, 'profiles', 'r*_%spmc_%s.csv' % (tag, kind)))
+                               if re.fullmatch(r'r\d+[a-z]*_%spmc_%s\.csv' % (tag, kind), os.path.basename(f)))
+    fetch, write = pick('fetch'), pick('write')
     if not fetch or not write:
         return None, None
 
