@@ -241,19 +241,29 @@ def pretrain_main(a, dtype, dev, rank, world):
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes).items()}
     model.load_state_dict(sd)
     model = model.to(dev).train()
-    ddp = D.wrap_model(model, dev, bf16_grads=(dtype == torch.bfloat16))
+    graphed = not a.eager            # the step as replayed HIP graphs (dsrg_amd.train_graph); --eager: the Python step under DDP
+    ddp = model if graphed else D.wrap_model(model, dev, bf16_grads=(dtype == torch.bfloat16))
     decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in ('bias', 'LayerNorm'))]
     nodecay = [p for n, p in model.named_parameters() if p.requires_grad and any(t in n for t in ('bias', 'LayerNorm'))]
     opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': nodecay, 'weight_decay': 0.0}],
-                            lr=5e-5, betas=(0.9, 0.98), fused=True)
+                            lr=5e-5, betas=(0.9, 0.98), fused=True, capturable=graphed)
     batches = {t: T(synth.pretrain_batch(PT_B, PT_L, 3, 200 + rank, t, min_steps=4, max_steps=7), dev) for t in PT_TASKS}
     last = {}
     params = [p for p in model.parameters() if p.requires_grad]      # walking the module tree costs ~1.4 ms of host time per step
+    if graphed:
+        from dsrg_amd.train_graph import GraphedTrainStep
+        gs = GraphedTrainStep(model, opt, 5.0, params=params, bf16_grads=(dtype == torch.bfloat16))
+        # one eager step + one capture per task (untimed); the timed steps hand the captured batches back: inputs resident
+        # in HBM in the buffers the step reads, as in the eager bench
+        static = {t: gs.static_batch(batches[t], t) for t in PT_TASKS}
 
     def step(i):
         task = PT_TASKS[i % len(PT_TASKS)]
         if world > 1:
             task = PT_TASKS[D.broadcast_task_id(PT_TASKS.index(task), dev)]
+        if graphed:
+            last[task] = gs.step(static[task], task)
+            return
         dbg = os.environ.get('DSRG_BENCH_HANG_DUMP')
         t_ = time.perf_counter()
         opt.zero_grad(set_to_none=True)
@@ -298,6 +308,8 @@ def pretrain_main(a, dtype, dev, rank, world):
                'unit': 'trajectories/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': 'BASELINE config[3]: R2R pre-training step, forward+backward+clip+AdamW, %s' % a.dtype, 'name': 'c4',
+                          'step': ('HIP graph replay per task (forward+backward+clip+AdamW captured once; %s)' % (
+                                       'one graph' if world == 1 else 'two graphs around one flat gradient all-reduce')) if graphed else 'eager Python step',
                           'host_threads': 'main + autograd thread on their own free cores' if a.no_pin else 'main + autograd thread pinned to one core',
                           'trajectories_per_gpu': PT_B, 'txt_len': PT_L, 'trajectory_steps_total': nsteps, 'dropout': cfg.hidden_dropout_prob,
                           'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else

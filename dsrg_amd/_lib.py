@@ -78,6 +78,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     'dsrg_abi_version': (C.c_int, []),
     'dsrg_init': (C.c_int, []),
+    'dsrg_set_dropout_offset': (C.c_int, [_P]),
     'dsrg_last_error': (C.c_char_p, []),
     'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
     'dsrg_gemm_nt_tiled': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _I, _I, _I, _P]),

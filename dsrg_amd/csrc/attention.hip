@@ -27,6 +27,7 @@ struct AttnArgs {
   // (dsrg_attn_problem_t::klens: no mask-building kernel in front of the attention launch)
   const int64_t* klens; int kseg;
   const int64_t* klens2;      // optional second lengths tensor, added to the first (REVERIE: view_lens + obj_lens)
+  const unsigned long long* seed_off;     // optional device word added to the seed (dsrg_set_dropout_offset)
 };
 // valid[b, key] from the bool mask or from the lengths
 __device__ __forceinline__ bool key_valid(const AttnArgs& a, int b, int key) {
@@ -71,6 +72,7 @@ struct AttnGroup {
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
   ATTN_PICK_PROBLEM(grp)
+  if constexpr (DROP) { if (a.seed_off) a.seed += *a.seed_off; }
   __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
   __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
@@ -198,6 +200,7 @@ template <bool DROP, bool SPREL>
 __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) void attention_mfma_kernel(const AttnGroup grp) {
   ATTN_STAMP(0);
   ATTN_PICK_PROBLEM(grp)
+  if constexpr (DROP) { if (a.seed_off) a.seed += *a.seed_off; }
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
   __shared__ float mt[KC];
@@ -453,7 +456,8 @@ __device__ __forceinline__ float mask_term(const AttnArgs& a, int b, int key, bo
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs ba) {
-  const AttnArgs& a = ba.f;
+  AttnArgs a = ba.f;
+  if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Vs[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
@@ -563,7 +567,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const AttnBwdArgs
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArgs ba) {
-  const AttnArgs& a = ba.f;
+  AttnArgs a = ba.f;
+  if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) float Ks[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Vs[KT * KPAD];
   __shared__ __attribute__((aligned(16))) float Qs[QPB * DH];
@@ -739,7 +744,8 @@ __device__ __forceinline__ bf16x8 tfrag(const char* St, int dt, int c16, int j, 
 
 template <bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBwdArgs ba) {
-  const AttnArgs& a = ba.f;
+  AttnArgs a = ba.f;
+  if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vs[KC * 128];
   __shared__ __attribute__((aligned(16))) char Kt[DH * VRS];
@@ -871,7 +877,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
 
 template <bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnBwdArgs ba) {
-  const AttnArgs& a = ba.f;
+  AttnArgs a = ba.f;
+  if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) char Qs[KC * 128];
   __shared__ __attribute__((aligned(16))) char Gs[KC * 128];
   __shared__ __attribute__((aligned(16))) char Qt[DH * VRS];
@@ -1040,7 +1047,8 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
     grp.a[grp.n++] = AttnArgs{p.Q, p.K, p.V, p.O, p.q_bs, p.k_bs, p.v_bs, p.o_bs, p.q_rs, p.k_rs, p.v_rs, p.o_rs,
                               mask_mode == DSRG_MASK_NONE ? nullptr : p.kmask, mask_mode, p.pair_dists, sprel_w, sprel_b, p.Nq, p.Nk, scale,
                               p.lse, NH, p_drop, seed + 0x632BE59BD9B4E019ull * (unsigned long long)i,
-                              mask_mode == DSRG_MASK_NONE ? nullptr : p.klens, p.kseg, mask_mode == DSRG_MASK_NONE ? nullptr : p.klens2};
+                              mask_mode == DSRG_MASK_NONE ? nullptr : p.klens, p.kseg, mask_mode == DSRG_MASK_NONE ? nullptr : p.klens2,
+                              p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr};
   }
   if (B == 0 || grp.n == 0) return DSRG_OK;
   const int qpb = mfma_ok ? 64 : QPB;           // query rows per workgroup
@@ -1110,7 +1118,8 @@ static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void*
              "dsrg_attention_bwd: misaligned pointer");
   if (B == 0 || Nq == 0) return DSRG_OK;
   AttnBwdArgs ba{{Q, K, V, const_cast<void*>(O), q_bs, k_bs, v_bs, o_bs, q_rs, k_rs, v_rs, o_rs, mask_mode == DSRG_MASK_NONE ? nullptr : kmask,
-                  mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH, p_drop, seed},
+                  mask_mode, pair_dists, sprel_w, sprel_b, Nq, Nk, scale, const_cast<float*>(lse), NH, p_drop, seed, nullptr, 0, nullptr,
+                  p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr},
                  dO, do_bs, do_rs, dQ, dK, dV, dq_bs, dk_bs, dv_bs, (int)dq_rs, (int)dk_rs, (int)dv_rs, delta_ws, dsprel};
   hipStream_t s = (hipStream_t)stream;
   dim3 gq((Nq + QPB - 1) / QPB, NH, B), gk((Nk + KT - 1) / KT, NH, B), block(256);

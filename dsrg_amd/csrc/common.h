@@ -118,6 +118,9 @@ __device__ __forceinline__ f32x2_t gelu_erf_short2(f32x2_t x) {
 
 // host side
 void dsrg_set_error(const char* fmt, ...);
+// device pointer registered with dsrg_set_dropout_offset() for the current device (NULL = none): a uint64 that every
+// dropout kernel adds to its seed, so that a captured training step draws new masks on every replay
+const unsigned long long* dsrg_dropout_offset_ptr();
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per (call site, device) under std::call_once: the entry points are
 // re-entrant (include/dsrg_hip.h), and the attribute belongs to each device's copy of the code object
 #define DSRG_MAX_DEVICES 16

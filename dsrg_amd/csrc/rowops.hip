@@ -14,6 +14,22 @@ void dsrg_set_error(const char* fmt, ...) {
 extern "C" const char* dsrg_last_error(void) { return g_err; }
 extern "C" int dsrg_abi_version(void) { return DSRG_ABI_VERSION; }
 
+// ---- dropout seed offset (include/dsrg_hip.h: dsrg_set_dropout_offset), one slot per device
+#include <atomic>
+static std::atomic<const unsigned long long*> g_drop_off[DSRG_MAX_DEVICES];
+const unsigned long long* dsrg_dropout_offset_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DSRG_MAX_DEVICES) return nullptr;
+  return g_drop_off[dev].load(std::memory_order_acquire);
+}
+extern "C" int dsrg_set_dropout_offset(const uint64_t* dev_ptr) {
+  int dev = 0;
+  DSRG_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < DSRG_MAX_DEVICES, "dsrg_set_dropout_offset: no current device");
+  DSRG_CHECK(((uintptr_t)dev_ptr & 7) == 0, "dsrg_set_dropout_offset: pointer must be 8-byte aligned");
+  g_drop_off[dev].store(reinterpret_cast<const unsigned long long*>(dev_ptr), std::memory_order_release);
+  return DSRG_OK;
+}
+
 namespace {
 
 constexpr int WPB = 4;        // waves (rows) per 256-thread block
@@ -56,6 +72,7 @@ struct LnArgs {
   float p_drop, inv_keep;
   unsigned long long seed;
   int tag[DSRG_MAX_GROUPS];
+  const unsigned long long* seed_off;     // optional device word added to the seed (dsrg_set_dropout_offset)
 };
 
 // NV = float4 chunks per lane (ceil(H / 256)), a template parameter so that every load of the row - x, the residual,
@@ -110,12 +127,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
     bt[i] = *reinterpret_cast<const float4*>(P.beta + c);
   }
   if constexpr (DROP) {       // dropout(x) before the residual add (BertSelfOutput / BertOutput, vilmodel.py:173-177, 213-217)
+    const unsigned long long seed = a.seed + (a.seed_off ? *a.seed_off : 0ull);
     const size_t base = ((size_t)a.tag[g] << 40) + (size_t)row * H;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const size_t c = base + min((i * 64 + lane) * 4, H - 4);
-      v[i].x *= drop_keep(a.seed, c, a.p_drop, a.inv_keep); v[i].y *= drop_keep(a.seed, c + 1, a.p_drop, a.inv_keep);
-      v[i].z *= drop_keep(a.seed, c + 2, a.p_drop, a.inv_keep); v[i].w *= drop_keep(a.seed, c + 3, a.p_drop, a.inv_keep);
+      v[i].x *= drop_keep(seed, c, a.p_drop, a.inv_keep); v[i].y *= drop_keep(seed, c + 1, a.p_drop, a.inv_keep);
+      v[i].z *= drop_keep(seed, c + 2, a.p_drop, a.inv_keep); v[i].w *= drop_keep(seed, c + 3, a.p_drop, a.inv_keep);
     }
   }
   if (res) {
@@ -623,6 +641,7 @@ static int layernorm_fwd_impl(const dsrg_ln_problem_t* problems, int nproblems, 
   LnArgs a;
   a.nprob = 0; a.H = H; a.eps = eps;
   a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+  a.seed_off = p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr;
   int blocks = 0;
   for (int i = 0; i < nproblems; ++i) {
     const dsrg_ln_problem_t& p = problems[i];

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const
 constexpr int LNB_MAXV = 4;
 // DROP: the forward ran  z = dropout(x) + res  (dsrg_layernorm_fwd_grouped_drop): the mask is recomputed from (seed, tag, row,
 // col); dz is the gradient of the residual, dzd = dz * keep / (1 - p) the gradient of x (the dense output in front of it).
-struct LnDrop { float p, inv_keep; unsigned long long seed; int tag; };
+struct LnDrop { float p, inv_keep; unsigned long long seed; int tag; const unsigned long long* seed_off; };
 template <typename TX, typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, int ldx, const T* __restrict__ res, int ldr,
                                                             const float* __restrict__ gamma, const T* __restrict__ dy, int lddy,
@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
   const int nv = (H + 255) / 256;
   const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
   float4 ag[LNB_MAXV], ab[LNB_MAXV], gm[LNB_MAXV];
+  if constexpr (DROP) {
+    if (dr.seed_off) dr.seed += *dr.seed_off;          // (dsrg_set_dropout_offset: the forward added the same word)
+  }
 #pragma unroll
   for (int i = 0; i < LNB_MAXV; ++i) {
     ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -306,7 +309,7 @@ static int layernorm_bwd_impl(const void* x, int ldx, const void* residual, int 
   const int rpb = 16;
   dim3 grid((M + rpb - 1) / rpb), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const LnDrop dr{p_drop, 1.0f / (1.0f - p_drop), seed, tag};
+  const LnDrop dr{p_drop, 1.0f / (1.0f - p_drop), seed, tag, p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr};
 #define DSRG_LNB(TX_, T_, DROP_)                                                                                                   \
   hipLaunchKernelGGL((layernorm_bwd_kernel<TX_, T_, DROP_>), grid, block, 0, s, (const TX_*)x, ldx, (const T_*)residual, ldr, gamma, \
                      (const T_*)dy, lddy, (T_*)dz, lddz, dgamma, dbeta, M, H, eps, rpb, dr, (T_*)dzd, lddzd)

@@ -1097,15 +1097,23 @@ class _SegmentWsumFn(torch.autograd.Function):
         return d0, d1, None, None, None
 
 
-def segment_wsum(in0, in1, dst, src, w, m):
-    """out[d] = sum_{e: dst_e = d} w_e * cat(in0, in1)[src_e]  (dst, src, w: host index arrays; m output rows).  One kernel
-    forward, the same kernel on the transposed incidence backward."""
+def segment_plan(dst, src, w, m, n, device):
+    """Device-resident incidence of a segment_wsum, built once on the host: the CSR over the m destinations (forward) and
+    the transposed one over the n source rows (backward).  A plan depends only on the index arrays, so a caller that
+    replays the same batch (a captured training step) builds it outside the replayed region and passes it in."""
+    return csr_by(dst, m, src, w, device), csr_by(src, n, dst, w, device)
+
+
+def segment_wsum(in0, in1, dst, src, w, m, plan=None):
+    """out[d] = sum_{e: dst_e = d} w_e * cat(in0, in1)[src_e]  (dst, src, w: host index arrays, or a `plan` from segment_plan;
+    m output rows).  One kernel forward, the same kernel on the transposed incidence backward."""
     dev = in0.device
     in0 = in0.reshape(-1, in0.shape[-1])
     if in1 is not None:
         in1 = in1.reshape(-1, in1.shape[-1])
-    fwd = csr_by(dst, m, src, w, dev)
+    n = in0.shape[0] + (in1.shape[0] if in1 is not None else 0)
+    if plan is None:
+        plan = (csr_by(dst, m, src, w, dev), csr_by(src, n, dst, w, dev) if _needs_grad((in0, in1)) else None)
     if _needs_grad((in0, in1)):
-        n = in0.shape[0] + (in1.shape[0] if in1 is not None else 0)
-        return _SegmentWsumFn.apply(in0, in1, fwd, csr_by(src, n, dst, w, dev), m)
-    return K.segment_wsum(in0, in1, *fwd, m)[0]
+        return _SegmentWsumFn.apply(in0, in1, plan[0], plan[1], m)
+    return K.segment_wsum(in0, in1, *plan[0], m)[0]

@@ -350,6 +350,21 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     return dq, dk, dv, dsp
 
 
+_DROP_OFF = {}
+
+
+def set_dropout_offset(t):
+    """Register (or, with None, clear) the int64 device word that every dropout kernel adds to its seed on `t`'s device
+    (dsrg_set_dropout_offset): a captured training step advances it once per replay.  The tensor is kept alive here."""
+    lib = _lib.load()
+    dev = torch.cuda.current_device() if t is None else _dev(t).device.index
+    if t is not None and (t.dtype != torch.int64 or t.numel() != 1):
+        raise _lib.DsrgHipError('set_dropout_offset: one int64 element')
+    with torch.cuda.device(dev):
+        _lib.check(lib.dsrg_set_dropout_offset(_p(t)), 'dsrg_set_dropout_offset')
+    _DROP_OFF[dev] = t
+
+
 def init():
     """dsrg_init() for the current device: resolve the library's static workspace outside any stream capture (required
     before attention_bwd_noalloc is captured into a HIP graph on this device)."""

@@ -24,6 +24,22 @@ from ._lib import ACT_GELU, ACT_RELU, MASK_NEG10000
 from .vilmodel import GlocalTextPathNavCMT as _Backbone, _cls_head, _dense_ln, _mod
 
 
+def _memo(b, key, build):
+    """Host-built index tensors of a batch (aggregation incidences, selections of masked tokens, the last step of every
+    trajectory, logit-fusion sources) depend only on the batch's own index data.  A batch that carries a dict under
+    '_prep' keeps them there: the first forward over it fills the dict, later ones - the captured training step of
+    dsrg_amd.train_graph replays the batch - find them and issue no host work, no host-to-device copy and no
+    data-dependent shape query.  Without '_prep' everything is built per call, as before."""
+    p = b.get('_prep')
+    if p is None:
+        return build()
+    if key not in p:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("batch['_prep'] lacks %r: run one eager forward over this batch before capturing it" % key)
+        p[key] = build()
+    return p[key]
+
+
 class GlocalTextPathCMT(_Backbone):
     PRETRAIN = True
 
@@ -66,13 +82,27 @@ class GlocalTextPathCMT(_Backbone):
             s0 += T
         return np.asarray(dst, np.int64), np.asarray(src, np.int64), np.asarray(w, np.float32)
 
+    def _build_gmap_plan(self, b, S, V, B, G, dev):
+        return Fn.segment_plan(*self.gmap_aggregation_indices(b['traj_step_lens'], b['traj_vpids'], b['traj_cand_vpids'], b['gmap_vpids'], V, G),
+                               B * G, S * V + S, dev)
+
+    @staticmethod
+    def _build_vp_plan(b, S, V, T, dev):
+        last_np = np.cumsum(np.asarray(b['traj_step_lens'], np.int64)) - 1
+        # token (i, 0) = zeros ([stop]), token (i, t >= 1) = view t-1 of trajectory i's last step: the same gather kernel
+        tt = np.arange(1, T)
+        dst = (np.arange(last_np.shape[0])[:, None] * T + tt[None]).reshape(-1)
+        src = (last_np[:, None] * V + (tt - 1)[None]).reshape(-1)
+        return (torch.from_numpy(last_np).to(dev),
+                Fn.segment_plan(dst, src, np.ones(dst.shape[0], np.float32), last_np.shape[0] * T, S * V, dev))
+
     def _gmap_input(self, W, pano, fused, b):
         cfg, cd = self.config, self.compute_dtype
         B, G = b['gmap_step_ids'].shape
         S, V, H = pano.shape
         dev = pano.device
-        dst, src, w = self.gmap_aggregation_indices(b['traj_step_lens'], b['traj_vpids'], b['traj_cand_vpids'], b['gmap_vpids'], V, G)
-        img = Fn.segment_wsum(pano.reshape(S * V, H), fused, dst, src, w, B * G)      # one gather kernel, no atomics
+        plan = _memo(b, 'gmap_plan', lambda: self._build_gmap_plan(b, S, V, B, G, dev))
+        img = Fn.segment_wsum(pano.reshape(S * V, H), fused, None, None, None, B * G, plan=plan)      # one gather kernel, no atomics
         g = Fn.embed_ln(B * G, H, cd, dev, base=img, feat=b['gmap_pos_fts'].float().reshape(B * G, -1).contiguous(),
                         Wf=W['gmap.pos.w'], bf=W['gmap.pos.b'], lnf=(W['gmap.pos.ln.g'], W['gmap.pos.ln.b']),
                         E1=W['gmap.step'], idx1=b['gmap_step_ids'].reshape(-1)).view(B, G, H)
@@ -83,16 +113,11 @@ class GlocalTextPathCMT(_Backbone):
         cfg, cd = self.config, self.compute_dtype
         S, V, H = pano.shape
         dev = pano.device
-        last_np = np.cumsum(np.asarray(b['traj_step_lens'], np.int64)) - 1
-        last = torch.from_numpy(last_np).to(dev)
-        B = last.shape[0]
         T = b['vp_pos_fts'].shape[1]                 # = max(last view_len) + 1  ([stop] first)
+        last, plan = _memo(b, 'vp_plan', lambda: self._build_vp_plan(b, S, V, T, dev))
+        B = last.shape[0]
         vp_lens = tok_lens.index_select(0, last) + 1
-        # token (i, 0) = zeros ([stop]), token (i, t >= 1) = view t-1 of trajectory i's last step: the same gather kernel
-        tt = np.arange(1, T)
-        dst = (np.arange(B)[:, None] * T + tt[None]).reshape(-1)
-        src = (last_np[:, None] * V + (tt - 1)[None]).reshape(-1)
-        img = Fn.segment_wsum(pano.reshape(S * V, H), None, dst, src, np.ones(dst.shape[0], np.float32), B * T)
+        img = Fn.segment_wsum(pano.reshape(S * V, H), None, None, None, None, B * T, plan=plan)
         v = Fn.embed_ln(B * T, H, cd, dev, base=img.reshape(B * T, H), feat=b['vp_pos_fts'].float().reshape(B * T, -1).contiguous(),
                         Wf=W['vp.pos.w'], bf=W['vp.pos.b'], lnf=(W['vp.pos.ln.g'], W['vp.pos.ln.b'])).view(B, T, H)
         vmask = (torch.arange(T, device=dev)[None] < vp_lens[:, None]).contiguous()
@@ -216,6 +241,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self._hwres = None
         return self._hw_resolve(plan)
 
+    def drop_grad_packs(self):
+        """forget the differentiable weight packs (and with them the autograd nodes of the step that made them)"""
+        self.bert._wgrad = None
+        self._hwres = None
+
     def _hw_resolve(self, plan):
         """one pack per parameter version and grad mode (see GlocalTextPathNavCMT._resolve_weights)"""
         W0, pk, _ = plan
@@ -249,14 +279,19 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward_mlm(self, b, compute_loss=True):   # pretrain_cmt.py:142-167
         W, cd = self._hw(), self.bert.compute_dtype
         txt = self.bert.forward_mlm(b)
-        sel = b['txt_labels'] != -1
-        h = txt[sel].to(cd).contiguous()
+        idx, labels = _memo(b, 'mlm_sel', lambda: self._build_mlm_sel(b))
+        h = txt.reshape(-1, txt.shape[-1]).index_select(0, idx).to(cd)
         h = Fn.linear(h, W['mlm.t.w'], W['mlm.t.b'], act=ACT_GELU, out_f32=True)
         h = Fn.layernorm(h, W['mlm.ln.g'], W['mlm.ln.b'], self.config.layer_norm_eps, out_dtype=cd)
         scores = Fn.linear(h, W['mlm.dec.w'], W['mlm.dec.b'], out_f32=True)
         if compute_loss:
-            return Fn.cross_entropy_rows(scores, b['txt_labels'][sel])
+            return Fn.cross_entropy_rows(scores, labels)
         return scores
+
+    @staticmethod
+    def _build_mlm_sel(b):                            # the masked positions, row-major as txt[labels != -1] lists them
+        idx = (b['txt_labels'].reshape(-1) != -1).nonzero().reshape(-1)
+        return idx, b['txt_labels'].reshape(-1).index_select(0, idx)
 
     def _region_logits(self, W, key, x):
         """RegionClassification (pretrain_cmt.py:12-23): Linear+ReLU in the GEMM epilogue -> LayerNorm -> Linear(H, n_classes)"""
@@ -266,15 +301,31 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return Fn.linear(h, W[key + '.l2.w'], W[key + '.l2.b'], out_f32=True)
 
     @staticmethod
-    def _token_slices(v, start, lens, T):
+    def _token_slices(b, key, v, start, lens, T, mask=None):
         """[B, T, H]: row i = v[i, start_i : start_i + lens_i] zero-padded (the reference's pad_tensors_wgrad over per-sample
-        slices, pretrain_cmt.py:191-194, 203-206, 313-317; slices are clipped at the end of v like Python slicing)."""
+        slices, pretrain_cmt.py:191-194, 203-206, 313-317; slices are clipped at the end of v like Python slicing).  With a
+        [B, T] bool `mask` only the masked rows, in row-major order: [n_masked, H] = slices[mask].  One row-gather kernel
+        (dsrg_segment_wsum) forward and one backward over an incidence built on the host from the lengths."""
         B, N, H = v.shape
-        pos = torch.arange(T, device=v.device)[None]
-        idx = start[:, None] + pos
-        ok = (pos < lens[:, None]) & (idx < N)
-        rows = torch.gather(v, 1, idx.clamp(max=N - 1)[..., None].expand(B, T, H))
-        return rows * ok[..., None].to(v.dtype), ok
+        plan, m = _memo(b, key, lambda: GlocalTextPathCMTPreTraining._build_slices(start, lens, T, B, N, mask, v.device))
+        if m == 0:
+            return v.new_zeros((0, H))
+        rows = Fn.segment_wsum(v.reshape(B * N, H), None, None, None, None, m, plan=plan)
+        return rows if mask is not None else rows.view(B, T, H)
+
+    @staticmethod
+    def _build_slices(start, lens, T, B, N, mask, dev):
+        st, ln = start.cpu().numpy().astype(np.int64), lens.cpu().numpy().astype(np.int64)
+        t = np.arange(T)[None]
+        ok = (t < ln[:, None]) & (st[:, None] + t < N)
+        src = (np.arange(B)[:, None] * N + st[:, None] + t)
+        if mask is None:
+            dst, m = (np.arange(B)[:, None] * T + t), B * T
+        else:
+            mk = mask.cpu().numpy().astype(bool)
+            dst, m = np.cumsum(mk.reshape(-1)).reshape(B, T) - 1, int(mk.sum())
+            ok &= mk
+        return Fn.segment_plan(dst[ok], src[ok], np.ones(int(ok.sum()), np.float32), m, B * N, dev), m
 
     def _last_lens(self, b, last):
         vl = b['traj_vp_view_lens'].index_select(0, last)
@@ -286,16 +337,16 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         _, v, last = self.bert.forward_backbone(b, return_gmap_embeds=False)
         vl, ol = self._last_lens(b, last)
         m = b['vp_view_mrc_masks']
-        ve, _ = self._token_slices(v, torch.ones_like(vl), vl, m.shape[1])          # [stop] at 0
-        logits = self._region_logits(W, 'image_classifier', ve[m].contiguous())
-        tgt = b['vp_view_probs'][m]
+        ve = self._token_slices(b, 'mrc_view_rows', v, torch.ones_like(vl), vl, m.shape[1], mask=m)     # [stop] at 0; = slices[m]
+        logits = self._region_logits(W, 'image_classifier', ve)
+        tgt = _memo(b, 'mrc_view_tgt', lambda: b['vp_view_probs'][m])
         ologits = otgt = None
         if b.get('traj_obj_img_fts') is not None:                                    # object regions (REVERIE), :202-213
             om = b['vp_obj_mrc_masks']
-            oe, _ = self._token_slices(v, vl + 1, ol, om.shape[1])
+            oe = self._token_slices(b, 'mrc_obj_rows', v, vl + 1, ol, om.shape[1], mask=om)
             key = 'obj_classifier' if getattr(self, 'obj_classifier', None) is not None else 'image_classifier'
-            ologits = self._region_logits(W, key, oe[om].contiguous())
-            otgt = b['vp_obj_probs'][om]
+            ologits = self._region_logits(W, key, oe)
+            otgt = _memo(b, 'mrc_obj_tgt', lambda: b['vp_obj_probs'][om])
         if not compute_loss:
             return logits, tgt, ologits, otgt
         loss = F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
@@ -305,9 +356,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
 
     def _og_logits(self, W, b, v, last):   # pretrain_cmt.py:313-321
         vl, ol = self._last_lens(b, last)
-        T = int(ol.max())
-        oe, _ = self._token_slices(v, vl + 1, ol, T)
-        sc = self._scores(W, 'og_head', oe.contiguous())
+        T = _memo(b, 'og_T', lambda: int(ol.max()))
+        oe = self._token_slices(b, 'og_rows', v, vl + 1, ol, T)
+        sc = self._scores(W, 'og_head', oe)
         return sc.masked_fill(torch.arange(T, device=v.device)[None] >= ol[:, None], -float('inf'))
 
     def forward_og(self, b, compute_loss=True):   # pretrain_cmt.py:296-327
@@ -336,6 +387,44 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         return Fn.cross_entropy_rows(gl, b['global_act_labels']) + Fn.cross_entropy_rows(ll, b['local_act_labels']) \
             + Fn.cross_entropy_rows(fl, b['global_act_labels'])
 
+    def _build_sap_fusion(self, b, G, T, dev):
+        cands = [[None] + list(c[-1]) for c in b['traj_cand_vpids']]
+        src, bw = self.bert.fusion_indices(b['gmap_vpids'], b['gmap_visited_masks'], cands, G, T, skip=1)
+        return torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev)
+
+    def prepare(self, batch, task):
+        """Fill batch['_prep'] with every host-built index tensor `forward(batch, task)` consumes (see _memo), from the batch
+        alone: what a data-loader worker runs ahead of the step so that the step itself issues kernels only
+        (dsrg_amd.train_graph replays it as a HIP graph).  Idempotent; returns the batch."""
+        b = batch
+        p = b.setdefault('_prep', {})
+        dev = b['traj_loc_fts'].device
+        S, V = b['traj_loc_fts'].shape[:2]
+        T = b['vp_pos_fts'].shape[1]
+        B, G = b['gmap_step_ids'].shape
+        memo = lambda key, build: _memo(b, key, build)
+        last, _ = memo('vp_plan', lambda: self.bert._build_vp_plan(b, S, V, T, dev))
+        if task.startswith('mlm') or task.startswith('sap') or task.startswith('valid_sap_og'):
+            memo('gmap_plan', lambda: self.bert._build_gmap_plan(b, S, V, B, G, dev))
+        if task.startswith('mlm'):
+            memo('mlm_sel', lambda: self._build_mlm_sel(b))
+        if task.startswith('sap') or task.startswith('valid_sap_og'):
+            memo('sap_fusion', lambda: self._build_sap_fusion(b, G, T, dev))
+        if task.startswith('mrc') or task.startswith('og') or task.startswith('valid_sap_og'):
+            vl, ol = self._last_lens(b, last)
+            if task.startswith('mrc'):
+                m = b['vp_view_mrc_masks']
+                memo('mrc_view_rows', lambda: self._build_slices(torch.ones_like(vl), vl, m.shape[1], B, T, m, dev))
+                memo('mrc_view_tgt', lambda: b['vp_view_probs'][m])
+                if b.get('traj_obj_img_fts') is not None:
+                    om = b['vp_obj_mrc_masks']
+                    memo('mrc_obj_rows', lambda: self._build_slices(vl + 1, ol, om.shape[1], B, T, om, dev))
+                    memo('mrc_obj_tgt', lambda: b['vp_obj_probs'][om])
+            else:
+                To = memo('og_T', lambda: int(ol.max()))
+                memo('og_rows', lambda: self._build_slices(vl + 1, ol, To, B, T, None, dev))
+        return b
+
     def _sap_logits(self, W, b, g, v, last):   # pretrain_cmt.py:248-285
         B, G, _ = g.shape
         T = v.shape[1]
@@ -345,7 +434,5 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         gmask = (torch.arange(G, device=dev)[None] < b['gmap_lens'][:, None]).contiguous()
         nav_last = b['traj_nav_types'].index_select(0, last)                      # [B,V]
         nav_ok = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), nav_last[:, :T - 1] == 1], 1).contiguous()
-        cands = [[None] + list(c[-1]) for c in b['traj_cand_vpids']]
-        src, bw = self.bert.fusion_indices(b['gmap_vpids'], b['gmap_visited_masks'], cands, G, T, skip=1)
-        return Fn.nav_logits(sg, sl, fr, gmask, b['gmap_visited_masks'].contiguous(), nav_ok,
-                             torch.from_numpy(src).to(dev), torch.from_numpy(bw).to(dev))
+        src, bw = _memo(b, 'sap_fusion', lambda: self._build_sap_fusion(b, G, T, dev))
+        return Fn.nav_logits(sg, sl, fr, gmask, b['gmap_visited_masks'].contiguous(), nav_ok, src, bw)

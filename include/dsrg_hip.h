@@ -33,6 +33,12 @@ const char* dsrg_last_error(void);
  * may load the code object and must not run inside a capture (the entry point then fails with DSRG_EINVAL and says so).
  * Idempotent and thread-safe.  No counterpart in the reference. */
 int dsrg_init(void);
+/* Dropout under hipGraph replay (training; no counterpart in the reference, whose eager torch.nn.Dropout draws from the
+ * device generator): every dropout kernel of the library - attention probabilities, hidden states in front of a residual
+ * LayerNorm, forward and backward - takes its seed by value, so a captured training step would replay ONE mask.  With a
+ * device pointer registered here (current device; NULL = off) they add *dev_ptr to the seed at run time: the captured step
+ * advances that word once per replay and draws a new mask each time, forward and backward still agreeing. */
+int dsrg_set_dropout_offset(const uint64_t* dev_ptr);
 
 /* ---- GEMM: C = act(A · Wᵀ + bias) [+ residual] ------------------------------------------------
  * Replaces every nn.Linear on the path (FT/vilmodel.py:111-113,169,195,209,338-340,555,577,622;

@@ -1096,3 +1096,48 @@ def test_nav_logits_with_object_grounding(K):
     b4 = K.nav_logits(g, l, f, gm, gv, vn, src, bw, o, vo)
     assert all(torch.equal(x, y) for x, y in zip(a, b4[:3]))
     assert torch.equal(b4[3], o.masked_fill(~vo, -float('inf')))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_seed_offset_word(K, dtype):
+    """dsrg_set_dropout_offset: every dropout kernel (attention forward / backward, hidden-state dropout in front of the
+    residual LayerNorm forward / backward) run with seed s and the device word holding k must equal the same kernel run
+    with seed s + k and no word: that is what lets a captured training step draw new masks on every replay."""
+    from dsrg_amd import functional as Fn
+    B, nh, Nq, Nk, p, seed, k_off = 2, 12, 38, 80, 0.1, 0x2345_6789, 5
+    H = nh * 64
+    q, kv = _r(B, Nq, H, dtype=dtype), _r(B, Nk, 2 * H, seed=1, dtype=dtype)
+    k, v = kv[..., :H], kv[..., H:]
+    kmask = (torch.arange(Nk)[None] < torch.tensor([Nk, 17])[:, None]).cuda()
+    do = _r(B, Nq, H, seed=11, dtype=dtype)
+    x, w, b = _r(300, 256, seed=3, dtype=dtype), _r(H, 256, seed=4, scale=0.05, dtype=dtype), _r(H, seed=5)
+    res, g, bt = _r(300, H, seed=6, dtype=dtype), 1 + _r(H, seed=7, scale=0.1), _r(H, seed=8, scale=0.1)
+    go = _r(300, H, seed=9, dtype=dtype)
+
+    def run(s):
+        out, lse = K.attention(q, k, v, nh, kmask, 1, None, None, None, want_lse=True, p_drop=p, seed=s)
+        dq, dk, dv, _ = K.attention_bwd(q, k, v, out, do, lse, nh, kmask, 1, None, None, None, p_drop=p, seed=s)
+        leaves = [t.clone().requires_grad_(True) for t in (x, w, res)]
+        orig = Fn.dropout_seed
+        Fn.dropout_seed = lambda: s
+        try:
+            y = Fn.linear_ln(leaves[0], leaves[1], b, g, bt, 1e-12, residual=leaves[2], p_drop=p)
+        finally:
+            Fn.dropout_seed = orig
+        y.backward(go)
+        return [out, dq, dk, dv, y.detach()] + [t.grad for t in leaves]
+
+    want = run(seed + k_off)
+    word = torch.full((1,), k_off, dtype=torch.int64, device='cuda')
+    K.set_dropout_offset(word)
+    try:
+        got = run(seed)
+        word.fill_(0)
+        plain = run(seed)
+    finally:
+        K.set_dropout_offset(None)
+    for a, c in zip(got, want):
+        assert torch.equal(a, c)
+    assert not torch.equal(plain[0], want[0]) and not torch.equal(plain[4], want[4])
+    for a, c in zip(run(seed), plain):         # cleared: the seed alone again
+        assert torch.equal(a, c)

@@ -1,0 +1,101 @@
+"""gpu: dsrg_amd.train_graph.GraphedTrainStep (one pre-training optimisation step replayed as a HIP graph) against the
+same steps run eagerly: losses and parameters after six steps (mlm / mrc / sap twice), fp32 compute so the comparison is
+tight; new dropout masks on every replay; prepare() fills everything the captured forward needs."""
+import pytest
+import torch
+
+from dsrg_amd import synth
+from tests import common
+from tests.test_oracle_pt_golden import PT_CFG
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dtype, **over):
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain import GlocalTextPathCMTPreTraining
+    m = GlocalTextPathCMTPreTraining(DSRGConfig(**dict(PT_CFG, **over)), compute_dtype=dtype)
+    m.load_state_dict(common.synth_sd('r2r_pt'))
+    return m.cuda().train()
+
+
+def _opt(m):
+    return torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.98), fused=True, capturable=True)
+
+
+def _batches():
+    gold = common.load_gold('r2r_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    return {t: common.to_t(synth.pretrain_batch(B, L, O, seed, t), 'cuda') for t in ('mlm', 'mrc', 'sap')}
+
+
+def test_graphed_step_matches_eager_steps():
+    from dsrg_amd.train_graph import GraphedTrainStep
+    from dsrg_amd import kernels as K
+    bs = _batches()
+    a, b = _model(torch.float32), _model(torch.float32)
+    oa, ob = _opt(a), _opt(b)
+    pa = [p for p in a.parameters() if p.requires_grad]
+    gs = GraphedTrainStep(b, ob, 5.0)
+    try:
+        la, lb = [], []
+        for it in range(3):                       # round 0 = eager + capture inside step(); rounds 1, 2 replay
+            for t in ('mlm', 'mrc', 'sap'):
+                oa.zero_grad(set_to_none=True)
+                loss = a(bs[t], t, compute_loss=True).mean()
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(pa, 5.0)
+                oa.step()
+                la.append(float(loss.detach()))
+                lb.append(float(gs.step(bs[t], t)))
+        assert len(gs.graphs) == 3
+        for x, y in zip(la, lb):
+            assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (la, lb)
+        worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(a.parameters(), b.parameters()))
+        sd0 = common.synth_sd('r2r_pt')
+        moved = max(float((p.detach() - sd0[k].cuda()).abs().max()) for k, p in a.state_dict().items() if p.dtype.is_floating_point)
+        assert moved > 1e-2 and worst <= 2e-4, (worst, moved)      # float atomics in the backward: run-to-run noise of ~5e-5
+        # an eager forward after replays sees the replayed optimizer steps (no stale captured pack)
+        a.eval(); b.eval()
+        with torch.no_grad():
+            x, y = a(bs['sap'], 'sap', compute_loss=False)[0], b(bs['sap'], 'sap', compute_loss=False)[0]
+        fin = torch.isfinite(x)
+        assert float((x[fin] - y[fin]).abs().max()) <= 1e-3
+        # a different batch object with the same shapes goes through the input copy, not a new capture
+        other = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in bs['sap'].items() if k != '_prep'}
+        b.train()
+        gs.step(other, 'sap')
+        assert len(gs.graphs) == 3
+    finally:
+        K.set_dropout_offset(None)
+
+
+def test_graphed_step_draws_new_dropout_masks_per_replay():
+    from dsrg_amd.train_graph import GraphedTrainStep
+    from dsrg_amd import kernels as K
+    bs = _batches()
+    m = _model(torch.bfloat16, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=0.0, weight_decay=0.0, fused=True, capturable=True)
+    gs = GraphedTrainStep(m, opt, 5.0)
+    try:
+        st = gs.static_batch(bs['sap'], 'sap')
+        losses = [float(gs.step(st, 'sap')) for _ in range(4)]
+        assert int(gs.seed_off) == 4
+        assert len(set(losses)) == 4, losses                  # lr = 0: only the masks differ between replays
+        assert max(losses) - min(losses) < 0.5 * abs(losses[0]) + 0.5
+    finally:
+        K.set_dropout_offset(None)
+
+
+def test_prepare_fills_what_the_forward_reads():
+    bs = _batches()
+    m = _model(torch.bfloat16)
+    for t, b in bs.items():
+        m.prepare(b, t)
+        keys = set(b['_prep'])
+        before = {k: b['_prep'][k] for k in keys}
+        loss = m(b, t, compute_loss=True)
+        assert set(b['_prep']) == keys, (t, set(b['_prep']) ^ keys)          # the forward built nothing more
+        assert all(b['_prep'][k] is before[k] for k in keys)
+        plain = m({k: v for k, v in b.items() if k != '_prep'}, t, compute_loss=True)
+        assert torch.equal(loss, plain)
