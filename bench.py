@@ -245,8 +245,12 @@ def pretrain_main(a, dtype, dev, rank, world):
     ddp = model if graphed else D.wrap_model(model, dev, bf16_grads=(dtype == torch.bfloat16))
     decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(t in n for t in ('bias', 'LayerNorm'))]
     nodecay = [p for n, p in model.named_parameters() if p.requires_grad and any(t in n for t in ('bias', 'LayerNorm'))]
-    opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': nodecay, 'weight_decay': 0.0}],
-                            lr=5e-5, betas=(0.9, 0.98), fused=True, capturable=graphed)
+    groups = [{'params': decay, 'weight_decay': 0.01}, {'params': nodecay, 'weight_decay': 0.0}]       # optim/misc.py:9-19
+    if a.torch_optim:         # A/B: torch's fused AdamW + clip_grad_norm_ (multi-tensor ATen kernels)
+        opt = torch.optim.AdamW(groups, lr=5e-5, betas=(0.9, 0.98), fused=True, capturable=graphed)
+    else:                     # the reference's AdamW + clip in three HIP launches (dsrg_amd/optim.py, csrc/optim.hip)
+        from dsrg_amd.optim import AdamW
+        opt = AdamW(groups, lr=5e-5, betas=(0.9, 0.98))
     batches = {t: T(synth.pretrain_batch(PT_B, PT_L, 3, 200 + rank, t, min_steps=4, max_steps=7), dev) for t in PT_TASKS}
     last = {}
     params = [p for p in model.parameters() if p.requires_grad]      # walking the module tree costs ~1.4 ms of host time per step
@@ -273,7 +277,10 @@ def pretrain_main(a, dtype, dev, rank, world):
         loss.backward()
         if dbg:
             torch.cuda.synchronize(); print('rank %d step %d backward done %.2f s' % (rank, i, time.perf_counter() - t_), file=sys.stderr, flush=True)
-        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        if a.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, 5.0)
+        else:
+            opt.clip_grad_norm(5.0)
         opt.step()
         last[task] = loss.detach()
 
@@ -310,6 +317,7 @@ def pretrain_main(a, dtype, dev, rank, world):
                'config': {'workload': 'BASELINE config[3]: R2R pre-training step, forward+backward+clip+AdamW, %s' % a.dtype, 'name': 'c4',
                           'step': ('HIP graph replay per task (forward+backward+clip+AdamW captured once; %s)' % (
                                        'one graph' if world == 1 else 'two graphs around one flat gradient all-reduce')) if graphed else 'eager Python step',
+                          'optimizer': 'torch.optim.AdamW(fused) + clip_grad_norm_' if a.torch_optim else 'dsrg_amd.optim.AdamW (reference AdamW semantics) + clip, 3 HIP launches',
                           'host_threads': 'main + autograd thread on their own free cores' if a.no_pin else 'main + autograd thread pinned to one core',
                           'trajectories_per_gpu': PT_B, 'txt_len': PT_L, 'trajectory_steps_total': nsteps, 'dropout': cfg.hidden_dropout_prob,
                           'parallelism': ('DDP x%d (RCCL all-reduce, bf16 gradient buckets)' % world if dist.get_backend() == 'nccl' else
@@ -647,6 +655,7 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch kernels from Python each step instead of replaying a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--torch-optim', action='store_true', help="c4: torch.optim.AdamW(fused) + clip_grad_norm_ instead of dsrg_amd.optim.AdamW (A/B)")
     ap.add_argument('--no-pin', action='store_true', help='c4: do not pin the main / autograd threads to one core (A/B)')
     a = ap.parse_args()
 

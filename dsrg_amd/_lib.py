@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class HeadTailProblem(C.Structure):
@@ -79,6 +79,10 @@ SIGNATURES = {
     'dsrg_abi_version': (C.c_int, []),
     'dsrg_init': (C.c_int, []),
     'dsrg_set_dropout_offset': (C.c_int, [_P]),
+    'dsrg_opt_chunk': (C.c_int, []),
+    'dsrg_grad_sumsq': (C.c_int, [_P, _P, _I, _P, _P]),
+    'dsrg_adamw_prepare': (C.c_int, [_P, _I, _F, _F, _P, _P, _I, _P, _P]),
+    'dsrg_adamw_step': (C.c_int, [_P, _P, _I, _P, _P, _P, C.c_double, C.c_double, C.c_double, _I, _P]),
     'dsrg_last_error': (C.c_char_p, []),
     'dsrg_gemm_nt': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _P]),
     'dsrg_gemm_nt_tiled': (C.c_int, [C.POINTER(GemmProblem), _I, _I, _I, _I, _I, _I, _I, _P]),

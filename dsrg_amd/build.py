@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsrg_hip.so')
-SOURCES = ['gemm.hip', 'rowops.hip', 'attention.hip', 'train.hip', 'train_rows.hip', 'graphmap.hip']
+SOURCES = ['gemm.hip', 'rowops.hip', 'attention.hip', 'train.hip', 'train_rows.hip', 'graphmap.hip', 'optim.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'dsrg_hip.h')]
 
 

@@ -41,14 +41,17 @@ _ZERO_CHUNK = 1 << 20          # fp32 elements per chunk (4 MiB)
 def zeros_f32(shape, device):
     """Small zero-initialised fp32 accumulator (column sums, LayerNorm / bias gradients, sprel gradients ...).  A training
     step needs ~300 of them; each torch.zeros is a fill launch plus ~8 us of host time, so they are carved out of 4 MiB
-    chunks that ONE fill zeroes (a chunk is handed out once and never reused: slices may live on as .grad).  Under HIP-graph
-    capture, or for large requests, this is torch.zeros."""
+    chunks that ONE fill zeroes (a chunk is handed out once and never reused: slices may live on as .grad).  For large
+    requests this is torch.zeros; under HIP-graph capture too, unless the capture runs inside zero_pool_capture_scope()."""
     n = 1
     for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
         n *= int(d)
-    if n > 65536 or not _ZERO_POOL_ON or torch.cuda.is_current_stream_capturing():
+    capturing = torch.cuda.is_current_stream_capturing()
+    if n > 65536 or not _ZERO_POOL_ON or (capturing and _CAPTURE_SCOPE[0] is None):
         return torch.zeros(shape, device=device, dtype=torch.float32)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), _raw_stream(torch.cuda.current_device()) if _raw_stream else 0)
+    if capturing:
+        key = key + (_CAPTURE_SCOPE[0],)
     st = _ZERO_POOL.get(key)
     na = (n + 63) // 64 * 64
     if st is None or st[1] + na > _ZERO_CHUNK:
@@ -56,6 +59,27 @@ def zeros_f32(shape, device):
     out = st[0][st[1]:st[1] + n].view(shape)
     st[1] += na
     return out
+
+
+_CAPTURE_SCOPE = [None]
+
+
+class zero_pool_capture_scope:
+    """`with zero_pool_capture_scope():` around ONE stream capture: zeros_f32 then carves its accumulators out of chunks that
+    are allocated and filled INSIDE the capture (graph-pool memory, one fill node per chunk, replayed before any of the
+    chunk's users), and that no other capture and no eager code will ever be handed."""
+    _n = 0
+
+    def __enter__(self):
+        zero_pool_capture_scope._n += 1
+        self.prev, _CAPTURE_SCOPE[0] = _CAPTURE_SCOPE[0], ('capture', zero_pool_capture_scope._n)
+        return self
+
+    def __exit__(self, *exc):
+        for k in [k for k in _ZERO_POOL if k[-1] == _CAPTURE_SCOPE[0]]:
+            del _ZERO_POOL[k]
+        _CAPTURE_SCOPE[0] = self.prev
+        return False
 
 
 def rows_ok(t):

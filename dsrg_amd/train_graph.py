@@ -80,9 +80,10 @@ class GraphedTrainStep:
         self.stream = torch.cuda.Stream(self.dev)
         self.seed_off = torch.zeros(1, dtype=torch.int64, device=self.dev)
         K.set_dropout_offset(self.seed_off)
+        self.native_opt = hasattr(optimizer, 'clip_grad_norm') and hasattr(optimizer, 'sync_hyper')
         for g in optimizer.param_groups:
-            if not g.get('capturable', False):
-                raise ValueError('GraphedTrainStep: construct the optimizer with capturable=True')
+            if not self.native_opt and not g.get('capturable', False):
+                raise ValueError('GraphedTrainStep: construct a torch optimizer with capturable=True (or use dsrg_amd.optim.AdamW)')
 
     # ------------------------------------------------------------------ pieces of a step
     def _fwd_bwd(self, batch, task):
@@ -90,7 +91,14 @@ class GraphedTrainStep:
         loss.backward()
         return loss.detach()
 
-    def _update(self):
+    def _update(self, grad_scale=1.0):
+        if self.native_opt:                      # dsrg_amd.optim.AdamW: norm, clip coefficient and update in three launches
+            self.opt.grad_scale = grad_scale
+            self.opt.clip_grad_norm(self.max_norm)
+            self.opt.step()
+            return
+        if grad_scale != 1.0:
+            torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], grad_scale)
         torch.nn.utils.clip_grad_norm_(self.params, self.max_norm)
         self.opt.step()
 
@@ -112,8 +120,7 @@ class GraphedTrainStep:
             flat = flat.to(torch.bfloat16) if self.bf16_grads else flat
             self._allreduce(flat)
             torch._foreach_copy_(grads, [f.view_as(g) for f, g in zip(flat.split([g.numel() for g in grads]), grads)])
-            torch._foreach_div_(grads, float(self.world))
-        self._update()
+        self._update(1.0 / self.world)
         return loss
 
     # ------------------------------------------------------------------ capture
@@ -125,7 +132,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         self._drop_packs()
         e.g1, e.g2, e.flat = torch.cuda.CUDAGraph(), None, None
-        with torch.cuda.graph(e.g1, pool=self.pool, stream=side):
+        with torch.cuda.graph(e.g1, pool=self.pool, stream=side), K.zero_pool_capture_scope():
             self.seed_off.add_(1)
             e.loss = self._fwd_bwd(e.static, task)
             e.grads = [p.grad for p in self.params if p.grad is not None]
@@ -140,11 +147,10 @@ class GraphedTrainStep:
             for p, v in zip(owners, f32.split([g.numel() for g in e.grads])):
                 p.grad = v.view_as(p)
             e.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(e.g2, pool=self.pool, stream=side):
+            with torch.cuda.graph(e.g2, pool=self.pool, stream=side), K.zero_pool_capture_scope():
                 if f32 is not e.flat:
                     f32.copy_(e.flat)
-                f32.div_(float(self.world))
-                self._update()
+                self._update(1.0 / self.world)
         return e
 
     def _drop_packs(self):
@@ -190,6 +196,8 @@ class GraphedTrainStep:
             return loss
         if batch is not e.static:
             torch._foreach_copy_(e.tensors, [t for _, t in _tensors(batch)])
+        if self.native_opt:
+            self.opt.sync_hyper()                # a schedule may have moved lr: device words, no recapture
         e.g1.replay()
         if e.g2 is not None:
             self._allreduce(e.flat)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 12
+#define DSRG_ABI_VERSION 13
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -39,6 +39,41 @@ int dsrg_init(void);
  * device pointer registered here (current device; NULL = off) they add *dev_ptr to the seed at run time: the captured step
  * advances that word once per replay and draws a new mask each time, forward and backward still agreeing. */
 int dsrg_set_dropout_offset(const uint64_t* dev_ptr);
+
+/* ---- optimizer step of the pre-training path: gradient-norm clipping + AdamW over every parameter in three launches.
+ * Replaces torch.nn.utils.clip_grad_norm_ (pretrain_src/train_r2r.py:283-289) and the reference's own AdamW.step()
+ * (pretrain_src/optim/adamw.py:30-92: m, v moving averages, denom = sqrt(v) + eps, step = lr * sqrt(1 - b2^t) / (1 - b1^t)
+ * when correct_bias, decoupled weight decay p -= lr * wd * p applied after the update).
+ * All tables live in device memory (the caller builds them once per set of tensors):
+ *   table   one entry per parameter tensor that has a gradient this step (fp32, contiguous);
+ *   blocks  int32 pairs (tensor index, chunk index), one per workgroup; a chunk is dsrg_opt_chunk() elements;
+ *   hyper   float pairs (lr, weight_decay) per parameter group - device words, so a schedule can move lr without recapture;
+ *   steps   int32 update counters, one per parameter (entry.step_idx), advanced by dsrg_adamw_prepare;
+ *   norm    float[2] written by dsrg_adamw_prepare: total gradient norm (after grad_scale), coefficient applied to g.
+ * Order per step: dsrg_grad_sumsq (optional: only when clipping) -> dsrg_adamw_prepare -> dsrg_adamw_step.  The gradients
+ * themselves are left unscaled (the coefficient is applied where the update reads them). */
+typedef struct {
+  void* p;              /* parameter, fp32 [numel] */
+  const void* g;        /* gradient, fp32 [numel] */
+  float* m;             /* exp_avg */
+  float* v;             /* exp_avg_sq */
+  int64_t numel;
+  int32_t group;        /* index into hyper */
+  int32_t step_idx;     /* index into steps */
+  int32_t vec_ok;       /* p, g, m, v all 16-byte aligned */
+  int32_t reserved_;
+} dsrg_opt_tensor_t;
+int dsrg_opt_chunk(void);
+/* partials[b] = sum of g^2 over block b's chunk */
+int dsrg_grad_sumsq(const dsrg_opt_tensor_t* table, const int32_t* blocks, int n_blocks, float* partials, hipStream_t stream);
+/* norm_out[0] = grad_scale * sqrt(sum partials); norm_out[1] = grad_scale * min(1, max_norm / (norm + 1e-6)) (n_partials = 0
+ * or max_norm <= 0: no clipping, coefficient = grad_scale); steps[table[i].step_idx] += 1 for i < n_tensors.
+ * grad_scale folds a pending division of the gradients (1 / world size after a summing all-reduce) into the same read. */
+int dsrg_adamw_prepare(const float* partials, int n_partials, float max_norm, float grad_scale, float* norm_out,
+                       const dsrg_opt_tensor_t* table, int n_tensors, int32_t* steps, hipStream_t stream);
+/* norm may be NULL (coefficient 1).  betas / eps are doubles: the reference rounds 1 - beta from double (Python scalars) */
+int dsrg_adamw_step(const dsrg_opt_tensor_t* table, const int32_t* blocks, int n_blocks, const float* hyper, const float* norm,
+                    const int32_t* steps, double beta1, double beta2, double eps, int correct_bias, hipStream_t stream);
 
 /* ---- GEMM: C = act(A · Wᵀ + bias) [+ residual] ------------------------------------------------
  * Replaces every nn.Linear on the path (FT/vilmodel.py:111-113,169,195,209,338-340,555,577,622;

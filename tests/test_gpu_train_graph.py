@@ -19,8 +19,12 @@ def _model(dtype, **over):
     return m.cuda().train()
 
 
-def _opt(m):
-    return torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.98), fused=True, capturable=True)
+def _opt(m, native=False):
+    ps = [p for p in m.parameters() if p.requires_grad]
+    if native:
+        from dsrg_amd.optim import AdamW
+        return AdamW(ps, lr=1e-4, betas=(0.9, 0.98), weight_decay=0.01)
+    return torch.optim.AdamW(ps, lr=1e-4, betas=(0.9, 0.98), fused=True, capturable=True)
 
 
 def _batches():
@@ -29,12 +33,13 @@ def _batches():
     return {t: common.to_t(synth.pretrain_batch(B, L, O, seed, t), 'cuda') for t in ('mlm', 'mrc', 'sap')}
 
 
-def test_graphed_step_matches_eager_steps():
+@pytest.mark.parametrize('native', [False, True], ids=['torch-adamw', 'dsrg-adamw'])
+def test_graphed_step_matches_eager_steps(native):
     from dsrg_amd.train_graph import GraphedTrainStep
     from dsrg_amd import kernels as K
     bs = _batches()
     a, b = _model(torch.float32), _model(torch.float32)
-    oa, ob = _opt(a), _opt(b)
+    oa, ob = _opt(a, native), _opt(b, native)
     pa = [p for p in a.parameters() if p.requires_grad]
     gs = GraphedTrainStep(b, ob, 5.0)
     try:
@@ -44,7 +49,11 @@ def test_graphed_step_matches_eager_steps():
                 oa.zero_grad(set_to_none=True)
                 loss = a(bs[t], t, compute_loss=True).mean()
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(pa, 5.0)
+                if native:
+                    oa.param_groups[0]['lr'] = ob.param_groups[0]['lr'] = 1e-4 * (1 + it)      # a moving schedule, no recapture
+                    oa.clip_grad_norm(5.0)
+                else:
+                    torch.nn.utils.clip_grad_norm_(pa, 5.0)
                 oa.step()
                 la.append(float(loss.detach()))
                 lb.append(float(gs.step(bs[t], t)))
