@@ -99,7 +99,8 @@ SIGNATURES = {
     'dsrg_layernorm_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     'dsrg_layernorm_fwd_grouped': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _P]),
     'dsrg_layernorm_fwd_grouped_drop': (C.c_int, [C.POINTER(LnProblem), _I, _I, _F, _I, _I, _F, C.c_uint64, _P]),
-    'dsrg_layernorm_bwd_drop': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _F, C.c_uint64, _I, _P]),
+    'dsrg_layernorm_bwd_drop': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _I, _I, _F, C.c_uint64, _I, _P]),
+    'dsrg_layernorm_bwd_blocks': (C.c_int, [_I]),
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
                                     _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_embed_ln_fwd_seg': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
@@ -116,7 +117,7 @@ SIGNATURES = {
     'dsrg_colsum_acc': (C.c_int, [_P, _I, _P, _I, _I, _I, _P]),
     'dsrg_act_fwd': (C.c_int, [_P, _P, _L, _I, _I, _P]),
     'dsrg_act_bwd': (C.c_int, [_P, _P, _P, _L, _I, _I, _P]),
-    'dsrg_layernorm_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P]),
+    'dsrg_layernorm_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _F, _I, _I, _P]),
     'dsrg_group_mean_bwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dsrg_head_tail_bwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _P]),

@@ -68,15 +68,31 @@ __device__ __forceinline__ void st4_nt(bf16_t* p, float4 v) {
   __builtin_nontemporal_store(u, reinterpret_cast<u2*>(p));
 }
 
+// Wave-wide (64-lane) all-reduce.  Four DPP steps fold each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: ~8 cycles each, no LDS), then the four row results are read as scalars and combined in the butterfly's own
+// association ((r0 + r1) + (r2 + r3)), so the value is bit-identical to the __shfl_xor butterfly this replaces - whose six
+// ds_bpermute round trips (~60-100 cycles each, dependent) were the critical path of every row kernel: LayerNorm backward
+// spends four reductions per row.  Every lane of the wave must be active (as with the butterfly).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_f32(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_mov_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141>(v);      // row_half_mirror
+  v += dpp_mov_f32<0x140>(v);      // row_mirror
+  return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_mov_f32<0xB1>(v));
+  v = fmaxf(v, dpp_mov_f32<0x4E>(v));
+  v = fmaxf(v, dpp_mov_f32<0x141>(v));
+  v = fmaxf(v, dpp_mov_f32<0x140>(v));
+  return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -122,22 +122,24 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const
 
 // LayerNorm backward.  z = x (+ res); zh = (z - mean) * rstd; y = zh*gamma + beta.
 //   dz = rstd * (g - mean(g) - zh * mean(g*zh)),  g = dy*gamma;   dgamma += sum_rows dy*zh;  dbeta += sum_rows dy
-// One wave per row, each block walks a strip of rows and keeps its dgamma/dbeta partials in registers, then one
-// atomic per column per block.
+// One wave per row; a block keeps its dgamma/dbeta partials in registers, then one atomic per column per block.
 constexpr int LNB_MAXV = 4;
 // DROP: the forward ran  z = dropout(x) + res  (dsrg_layernorm_fwd_grouped_drop): the mask is recomputed from (seed, tag, row,
 // col); dz is the gradient of the residual, dzd = dz * keep / (1 - p) the gradient of x (the dense output in front of it).
 struct LnDrop { float p, inv_keep; unsigned long long seed; int tag; const unsigned long long* seed_off; };
-template <typename TX, typename T, bool DROP = false>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, int ldx, const T* __restrict__ res, int ldr,
+// v2 (round 3): 8 waves per block, R rows per wave held in registers at once and processed in ONE pass - all of a wave's loads
+// are in flight together, then the four row reductions, then the stores - instead of 4 waves walking 4 rows each one after the
+// other (one memory round trip per row: 12-17 us per launch for 2-18 MB of traffic).  R = 1 for short inputs (more blocks).
+constexpr int LNB_WAVES = 8;
+template <typename TX, typename T, bool DROP, int R>
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const TX* __restrict__ x, int ldx, const T* __restrict__ res, int ldr,
                                                             const float* __restrict__ gamma, const T* __restrict__ dy, int lddy,
-                                                            T* __restrict__ dz, int lddz, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int H, float eps, int rows_per_block, LnDrop dr = LnDrop{},
-                                                            T* __restrict__ dzd = nullptr, int lddzd = 0) {
-  __shared__ float red[2][4][1024];
+                                                            T* __restrict__ dz, int lddz, float* __restrict__ partials,
+                                                            int M, int H, float eps, LnDrop dr, T* __restrict__ dzd, int lddzd) {
+  __shared__ float red[LNB_WAVES][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (H + 255) / 256;
-  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  const int row0 = (blockIdx.x * LNB_WAVES + wave) * R;
   float4 ag[LNB_MAXV], ab[LNB_MAXV], gm[LNB_MAXV];
   if constexpr (DROP) {
     if (dr.seed_off) dr.seed += *dr.seed_off;          // (dsrg_set_dropout_offset: the forward added the same word)
@@ -148,23 +150,41 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     const int c = (i * 64 + lane) * 4;
     gm[i] = (i < nv && c < H) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int row = m0 + wave; row < m1; row += 4) {
-    float4 z[LNB_MAXV], g[LNB_MAXV], kp[DROP ? LNB_MAXV : 1];
+  float4 z[R][LNB_MAXV], g[R][LNB_MAXV], rs[R][LNB_MAXV];
+  // every load of the wave's rows first
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int row = row0 + j;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      z[j][i] = g[j][i] = rs[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nv && c < H && row < M) {
+        z[j][i] = ld4(x + (size_t)row * ldx + c);
+        if (res) rs[j][i] = ld4(res + (size_t)row * ldr + c);
+        g[j][i] = ld4(dy + (size_t)row * lddy + c);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int row = row0 + j;
+    if (row >= M) continue;                     // wave-uniform
+    float4 kp[DROP ? LNB_MAXV : 1];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
-        z[i] = ld4(x + (size_t)row * ldx + c);
+        float4& zz = z[j][i];
         if constexpr (DROP) {
           const size_t e = ((size_t)dr.tag << 40) + (size_t)row * H + c;
           kp[i] = make_float4(drop_keep(dr.seed, e, dr.p, dr.inv_keep), drop_keep(dr.seed, e + 1, dr.p, dr.inv_keep),
                               drop_keep(dr.seed, e + 2, dr.p, dr.inv_keep), drop_keep(dr.seed, e + 3, dr.p, dr.inv_keep));
-          z[i].x *= kp[i].x; z[i].y *= kp[i].y; z[i].z *= kp[i].z; z[i].w *= kp[i].w;
+          zz.x *= kp[i].x; zz.y *= kp[i].y; zz.z *= kp[i].z; zz.w *= kp[i].w;
         }
-        if (res) { const float4 r = ld4(res + (size_t)row * ldr + c); z[i].x += r.x; z[i].y += r.y; z[i].z += r.z; z[i].w += r.w; }
-        g[i] = ld4(dy + (size_t)row * lddy + c);
-        s += z[i].x + z[i].y + z[i].z + z[i].w;
+        zz.x += rs[j][i].x; zz.y += rs[j][i].y; zz.z += rs[j][i].z; zz.w += rs[j][i].w;
+        s += zz.x + zz.y + zz.z + zz.w;
       }
     }
     const float mean = wave_sum(s) / (float)H;
@@ -173,8 +193,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
-        z[i].x -= mean; z[i].y -= mean; z[i].z -= mean; z[i].w -= mean;
-        ss += z[i].x * z[i].x + z[i].y * z[i].y + z[i].z * z[i].z + z[i].w * z[i].w;
+        float4& zz = z[j][i];
+        zz.x -= mean; zz.y -= mean; zz.z -= mean; zz.w -= mean;
+        ss += zz.x * zz.x + zz.y * zz.y + zz.z * zz.z + zz.w * zz.w;
       }
     }
     const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
@@ -183,12 +204,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
-        z[i].x *= rstd; z[i].y *= rstd; z[i].z *= rstd; z[i].w *= rstd;          // zh
-        ab[i].x += g[i].x; ab[i].y += g[i].y; ab[i].z += g[i].z; ab[i].w += g[i].w;
-        ag[i].x += g[i].x * z[i].x; ag[i].y += g[i].y * z[i].y; ag[i].z += g[i].z * z[i].z; ag[i].w += g[i].w * z[i].w;
-        g[i].x *= gm[i].x; g[i].y *= gm[i].y; g[i].z *= gm[i].z; g[i].w *= gm[i].w;
-        sg += g[i].x + g[i].y + g[i].z + g[i].w;
-        sgz += g[i].x * z[i].x + g[i].y * z[i].y + g[i].z * z[i].z + g[i].w * z[i].w;
+        float4& zz = z[j][i];
+        float4& gg = g[j][i];
+        zz.x *= rstd; zz.y *= rstd; zz.z *= rstd; zz.w *= rstd;          // zh
+        ab[i].x += gg.x; ab[i].y += gg.y; ab[i].z += gg.z; ab[i].w += gg.w;
+        ag[i].x += gg.x * zz.x; ag[i].y += gg.y * zz.y; ag[i].z += gg.z * zz.z; ag[i].w += gg.w * zz.w;
+        gg.x *= gm[i].x; gg.y *= gm[i].y; gg.z *= gm[i].z; gg.w *= gm[i].w;
+        sg += gg.x + gg.y + gg.z + gg.w;
+        sgz += gg.x * zz.x + gg.y * zz.y + gg.z * zz.z + gg.w * zz.w;
       }
     }
     const float mg = wave_sum(sg) / (float)H, mgz = wave_sum(sgz) / (float)H;
@@ -196,29 +219,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     for (int i = 0; i < LNB_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < H) {
-        const float4 d = make_float4(rstd * (g[i].x - mg - z[i].x * mgz), rstd * (g[i].y - mg - z[i].y * mgz),
-                                     rstd * (g[i].z - mg - z[i].z * mgz), rstd * (g[i].w - mg - z[i].w * mgz));
+        const float4 zz = z[j][i], gg = g[j][i];
+        const float4 d = make_float4(rstd * (gg.x - mg - zz.x * mgz), rstd * (gg.y - mg - zz.y * mgz),
+                                     rstd * (gg.z - mg - zz.z * mgz), rstd * (gg.w - mg - zz.w * mgz));
         if (dz) st4(dz + (size_t)row * lddz + c, d);
         if constexpr (DROP) st4(dzd + (size_t)row * lddzd + c, make_float4(d.x * kp[i].x, d.y * kp[i].y, d.z * kp[i].z, d.w * kp[i].w));
       }
     }
   }
-  // combine the 4 waves' partials, one atomic per column
+  // combine the waves' partials (dgamma, then dbeta through the same LDS panel) into this block's row of the partial table
+  // [blocks][2][H]; layernorm_bwd_reduce_kernel sums the table.  (Float atomics on dgamma / dbeta - 2H addresses, 48 cache
+  // lines - were the whole cost of this kernel: 15-34 us per launch, proportional to the number of blocks.)
 #pragma unroll
-  for (int i = 0; i < LNB_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) {
-      *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[i];
-      *reinterpret_cast<float4*>(&red[1][wave][c]) = ab[i];
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (i < nv && c < H) *reinterpret_cast<float4*>(&red[wave][c]) = pass ? ab[i] : ag[i];
     }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += LNB_WAVES * 64) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) a += red[w][c];
+      partials[((size_t)blockIdx.x * 2 + pass) * H + c] = a;
+    }
   }
 }
 
+// out[c] = sum_b partials[b][c] for the 2H columns (dgamma | dbeta): 32 columns x 32 row groups per block (a thread reads
+// nblk / 32 values, all loads independent), LDS tree over the groups; fixed order
+constexpr int LNR_COLS = 32, LNR_GROUPS = 32;
+__global__ __launch_bounds__(LNR_COLS * LNR_GROUPS) void layernorm_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int H,
+                                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[LNR_GROUPS][LNR_COLS + 1];
+  const int cl = threadIdx.x % LNR_COLS, rg = threadIdx.x / LNR_COLS;
+  const int c = blockIdx.x * LNR_COLS + cl;            // 2H is a multiple of 64
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = rg;
+  for (; b + 3 * LNR_GROUPS < nblk; b += 4 * LNR_GROUPS) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += partials[(size_t)(b + LNR_GROUPS * u) * 2 * H + c];
+  }
+  for (; b < nblk; b += LNR_GROUPS) a[0] += partials[(size_t)b * 2 * H + c];
+  red[rg][cl] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+#pragma unroll
+  for (int o = LNR_GROUPS / 2; o > 0; o >>= 1) {
+    if (rg < o) red[rg][cl] += red[rg + o][cl];
+    __syncthreads();
+  }
+  if (rg == 0) {
+    if (c < H) dgamma[c] = red[0][cl]; else dbeta[c - H] = red[0][cl];
+  }
+}
+
+inline int lnb_rows_per_wave(int M) { return M <= 8192 ? 1 : 2; }        // one row per wave until the partial table outgrows the rows it saves
+inline int lnb_blocks(int M) { const int r = LNB_WAVES * lnb_rows_per_wave(M); return (M + r - 1) / r; }
 inline bool okdt(int d) { return d == DSRG_F32 || d == DSRG_BF16; }
 
 }  // namespace
@@ -296,39 +354,48 @@ extern "C" int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, 
   return DSRG_OK;
 }
 
+extern "C" int dsrg_layernorm_bwd_blocks(int M) { return M > 0 ? lnb_blocks(M) : 0; }
+
 static int layernorm_bwd_impl(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
-                              void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps, int in_dtype,
-                              int dtype, float p_drop, unsigned long long seed, int tag, void* stream) {
-  DSRG_CHECK(x && gamma && dy && dgamma && dbeta && okdt(in_dtype) && okdt(dtype), "dsrg_layernorm_bwd: bad pointer or dtype");
+                              void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, float* partials, int M, int H, float eps,
+                              int in_dtype, int dtype, float p_drop, unsigned long long seed, int tag, void* stream) {
+  DSRG_CHECK(x && gamma && dy && dgamma && dbeta && partials && okdt(in_dtype) && okdt(dtype), "dsrg_layernorm_bwd: bad pointer or dtype");
   DSRG_CHECK(in_dtype == DSRG_F32 || in_dtype == dtype, "dsrg_layernorm_bwd: in_dtype must be f32 or equal dtype");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddz % 4 == 0 && (!residual || ldr % 4 == 0), "dsrg_layernorm_bwd: bad H / leading dims");
   DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f && tag >= 0 && tag < DSRG_MAX_GROUPS, "dsrg_layernorm_bwd: p_drop=%g out of [0,1) or bad tag %d", (double)p_drop, tag);
   const bool drop = p_drop > 0.f;
   DSRG_CHECK(drop ? (dzd != nullptr && lddzd >= H && lddzd % 4 == 0) : dz != nullptr, "dsrg_layernorm_bwd: missing gradient output");
-  if (M <= 0) return DSRG_OK;
-  const int rpb = 16;
-  dim3 grid((M + rpb - 1) / rpb), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (M <= 0) {
+    (void)hipMemsetAsync(dgamma, 0, (size_t)H * 4, s);
+    (void)hipMemsetAsync(dbeta, 0, (size_t)H * 4, s);
+    return DSRG_OK;
+  }
   const LnDrop dr{p_drop, 1.0f / (1.0f - p_drop), seed, tag, p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr};
-#define DSRG_LNB(TX_, T_, DROP_)                                                                                                   \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<TX_, T_, DROP_>), grid, block, 0, s, (const TX_*)x, ldx, (const T_*)residual, ldr, gamma, \
-                     (const T_*)dy, lddy, (T_*)dz, lddz, dgamma, dbeta, M, H, eps, rpb, dr, (T_*)dzd, lddzd)
+  const int R = lnb_rows_per_wave(M);
+  dim3 grid(lnb_blocks(M)), block(LNB_WAVES * 64);
+#define DSRG_LNB2(TX_, T_, DROP_, R_)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<TX_, T_, DROP_, R_>), grid, block, 0, s, (const TX_*)x, ldx, (const T_*)residual, ldr, gamma, \
+                     (const T_*)dy, lddy, (T_*)dz, lddz, partials, M, H, eps, dr, (T_*)dzd, lddzd)
+#define DSRG_LNB(TX_, T_, DROP_) do { if (R == 1) DSRG_LNB2(TX_, T_, DROP_, 1); else DSRG_LNB2(TX_, T_, DROP_, 2); } while (0)
   if (in_dtype == DSRG_F32 && dtype == DSRG_F32) { if (drop) DSRG_LNB(float, float, true); else DSRG_LNB(float, float, false); }
   else if (in_dtype == DSRG_F32) { if (drop) DSRG_LNB(float, bf16_t, true); else DSRG_LNB(float, bf16_t, false); }
   else { if (drop) DSRG_LNB(bf16_t, bf16_t, true); else DSRG_LNB(bf16_t, bf16_t, false); }
+#undef DSRG_LNB2
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3(2 * H / LNR_COLS), dim3(LNR_COLS * LNR_GROUPS), 0, s, partials, (int)grid.x, H, dgamma, dbeta);
 #undef DSRG_LNB
   DSRG_LAUNCH_CHECK("dsrg_layernorm_bwd");
   return DSRG_OK;
 }
 
 extern "C" int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
-                                  void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps, int in_dtype, int dtype,
-                                  void* stream) {
-  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, nullptr, 0, dgamma, dbeta, M, H, eps, in_dtype, dtype, 0.f, 0, 0, stream);
+                                  void* dz, int lddz, float* dgamma, float* dbeta, float* partials, int M, int H, float eps, int in_dtype,
+                                  int dtype, void* stream) {
+  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, nullptr, 0, dgamma, dbeta, partials, M, H, eps, in_dtype, dtype, 0.f, 0, 0, stream);
 }
 
 extern "C" int dsrg_layernorm_bwd_drop(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
-                                       void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps,
-                                       int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream) {
-  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, dzd, lddzd, dgamma, dbeta, M, H, eps, in_dtype, dtype, p_drop, seed, tag, stream);
+                                       void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, float* partials, int M, int H,
+                                       float eps, int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream) {
+  return layernorm_bwd_impl(x, ldx, residual, ldr, gamma, dy, lddy, dz, lddz, dzd, lddzd, dgamma, dbeta, partials, M, H, eps, in_dtype, dtype, p_drop, seed, tag, stream);
 }

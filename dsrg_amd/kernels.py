@@ -712,19 +712,20 @@ def layernorm_bwd(x, residual, gamma, dy, eps, p_drop=0.0, seed=0, tag=0, want_d
     M, ldx = _rows(x)
     H = x.shape[-1]
     dy = rows_ok(dy)
-    dgb = zeros_f32((2, H), x.device)
+    dgb = torch.empty((2, H), device=x.device, dtype=torch.float32)          # written, not accumulated (ABI 13)
     dg, db = dgb[0], dgb[1]
+    part = torch.empty(max(1, lib.dsrg_layernorm_bwd_blocks(M)) * 2 * H, device=x.device, dtype=torch.float32)
     ldr = _rows(residual)[1] if residual is not None else 0
     if p_drop > 0.0:
         dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype) if want_dz else None
         dzd = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
         _lib.check(lib.dsrg_layernorm_bwd_drop(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dzd)[1], _p(dzd),
-                                               _rows(dzd)[1], _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), float(p_drop), int(seed), int(tag),
+                                               _rows(dzd)[1], _p(dg), _p(db), _p(part), M, H, float(eps), _dt(x), _dt(dy), float(p_drop), int(seed), int(tag),
                                                _stream()), 'dsrg_layernorm_bwd_drop')
         return dz, dzd, dg, db
     dz = torch.empty(x.shape, device=x.device, dtype=dy.dtype)
     _lib.check(lib.dsrg_layernorm_bwd(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(dy), _rows(dy)[1], _p(dz), _rows(dz)[1],
-                                      _p(dg), _p(db), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')
+                                      _p(dg), _p(db), _p(part), M, H, float(eps), _dt(x), _dt(dy), _stream()), 'dsrg_layernorm_bwd')
     return dz, dg, db
 
 

@@ -518,10 +518,14 @@ int dsrg_segment_wsum(const void* in0, int ld0, int n0, const void* in1, int ld1
                       int dtype, void* stream);
 
 /* LayerNorm backward for out = LN(x [+ residual]) * gamma + beta:
- *   dz (= dx = dresidual, stored as `dtype`), dgamma / dbeta accumulated with float atomics into zeroed fp32 [H].
+ *   dz (= dx = dresidual, stored as `dtype`); dgamma / dbeta fp32 [H] are WRITTEN (ABI 13; they were accumulated with float
+ *   atomics before, and those atomics - 2H addresses shared by every workgroup - were the kernel's whole cost): each workgroup
+ *   stores its column sums into `partials` (uninitialised fp32 workspace of dsrg_layernorm_bwd_blocks(M) * 2 * H elements) and
+ *   a second launch sums the table in a fixed order, so the result is also run-to-run deterministic.
  * x is `in_dtype` (fp32 pre-LN sums or `dtype`), residual / dy / dz are `dtype`. */
+int dsrg_layernorm_bwd_blocks(int M);
 int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy,
-                       int lddy, void* dz, int lddz, float* dgamma, float* dbeta, int M, int H, float eps,
+                       int lddy, void* dz, int lddz, float* dgamma, float* dbeta, float* partials, int M, int H, float eps,
                        int in_dtype, int dtype, void* stream);
 /* Hidden-state dropout fused into the residual LayerNorm (training; BertSelfOutput / BertOutput, FT/vilmodel.py:173-177,
  * 213-217: LayerNorm(dropout(dense(h)) + input)).  The keep decision of element (problem tag, row, col) is a counter-based
@@ -532,8 +536,8 @@ int dsrg_layernorm_bwd(const void* x, int ldx, const void* residual, int ldr, co
 int dsrg_layernorm_fwd_grouped_drop(const dsrg_ln_problem_t* problems, int nproblems, int H, float eps, int in_dtype,
                                     int out_dtype, float p_drop, uint64_t seed, void* stream);
 int dsrg_layernorm_bwd_drop(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
-                            void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, int M, int H, float eps,
-                            int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream);
+                            void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, float* partials, int M, int H,
+                            float eps, int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream);
 
 #ifdef __cplusplus
 }
