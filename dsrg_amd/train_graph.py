@@ -59,7 +59,7 @@ def signature(batch):
 
 
 class _Entry:
-    __slots__ = ('static', 'tensors', 'g1', 'g2', 'loss', 'flat', 'grads')
+    __slots__ = ('static', 'tensors', 'g1', 'g2', 'loss', 'flat', 'grads', 'f32')
 
 
 class GraphedTrainStep:
@@ -131,7 +131,7 @@ class GraphedTrainStep:
         side = self.stream
         self.opt.zero_grad(set_to_none=True)
         self._drop_packs()
-        e.g1, e.g2, e.flat = torch.cuda.CUDAGraph(), None, None
+        e.g1, e.g2, e.flat, e.f32 = torch.cuda.CUDAGraph(), None, None, None
         with torch.cuda.graph(e.g1, pool=self.pool, stream=side), K.zero_pool_capture_scope():
             self.seed_off.add_(1)
             e.loss = self._fwd_bwd(e.static, task)
@@ -144,6 +144,7 @@ class GraphedTrainStep:
         if self.world > 1:
             owners = [p for p in self.params if p.grad is not None]
             f32 = e.flat if e.flat.dtype == torch.float32 else torch.empty(e.flat.numel(), dtype=torch.float32, device=self.dev)
+            e.f32 = f32            # graph 2 reads and writes it on every replay: it must outlive the parameters' .grad views
             for p, v in zip(owners, f32.split([g.numel() for g in e.grads])):
                 p.grad = v.view_as(p)
             e.g2 = torch.cuda.CUDAGraph()
