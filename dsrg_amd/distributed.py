@@ -129,7 +129,10 @@ def pin_step_threads(local_rank=0, local_world=1):
     every forward -> backward -> optimizer hand-over pays a cross-core wake-up on cold caches (measured on the pre-training
     step: 18.4 ms per step on two cores, 16.1 on one, same binary, same box).  Threads that already exist (RCCL / gloo
     progress threads, created by init_process_group) keep their mask.  Returns the previous mask (restore with
-    os.sched_setaffinity(0, mask)), or None where the platform has no affinity call."""
+    os.sched_setaffinity(0, mask)), or None where the platform has no affinity call.
+    Inheritance cuts both ways: EVERY thread created while the pin is in force starts on that one core - intra-op pools
+    (torch.set_num_threads takes effect at the first parallel op), DataLoader workers, a CPU baseline.  Create such pools
+    before calling this (bench.py warms torch's pool first), or restore the mask before creating them."""
     if not hasattr(os, 'sched_getaffinity'):
         return None
     allowed = sorted(os.sched_getaffinity(0))
