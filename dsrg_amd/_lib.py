@@ -79,6 +79,9 @@ SIGNATURES = {
     'dsrg_abi_version': (C.c_int, []),
     'dsrg_init': (C.c_int, []),
     'dsrg_set_dropout_offset': (C.c_int, [_P]),
+    'dsrg_kl_rows_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _P]),
+    'dsrg_kl_rows_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_dropout_add': (C.c_int, [_P, _P, _P, _L, _I, _F, C.c_uint64, _P]),
     'dsrg_opt_chunk': (C.c_int, []),
     'dsrg_grad_sumsq': (C.c_int, [_P, _P, _I, _P, _P]),
     'dsrg_adamw_prepare': (C.c_int, [_P, _I, _F, _F, _P, _P, _I, _P, _P]),

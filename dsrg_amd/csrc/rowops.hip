@@ -593,6 +593,45 @@ __global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restric
   for (int j = N + threadIdx.x; j < ldd; j += 256) Elem<OutT>::st(out + j, 0.f);     // padding columns of a wider buffer
 }
 
+// ---- KL rows (the MRC loss tail, pretrain_cmt.py:215-226: F.kl_div(F.log_softmax(logits, -1), target, reduction='none').sum(1)).
+// One wave per row (4 rows per workgroup); N = 1000 / 1601 classes.
+//   forward : lse_r; loss_r = sum_c [t > 0] t * (log t - (x - lse_r))             (xlogy(t, t) - t * log_softmax(x))
+//   backward: dx[r, c] = g_r * (exp(x - lse_r) * sum_c t - t)
+__global__ __launch_bounds__(256) void kl_rows_fwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ target, int ldt,
+                                                          float* __restrict__ lse_rows, float* __restrict__ loss_rows, int R, int N) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* row = logits + (size_t)r * ld;
+  const float* tr = target + (size_t)r * ldt;
+  float m = -INFINITY;
+  for (int j = lane; j < N; j += 64) m = fmaxf(m, row[j]);
+  m = wave_max(m);
+  float s = 0.f, a = 0.f, st = 0.f;            // sum exp, sum t * (log t - x), sum t
+  for (int j = lane; j < N; j += 64) {
+    const float x = row[j], t = tr[j];
+    s += __expf(x - m);
+    if (t > 0.f) a += t * (logf(t) - x);
+    st += t;
+  }
+  s = wave_sum(s); a = wave_sum(a); st = wave_sum(st);
+  const float lse = m + logf(s);
+  if (lane == 0) { lse_rows[r] = lse; loss_rows[r] = a + st * lse; }
+}
+__global__ __launch_bounds__(256) void kl_rows_bwd_kernel(const float* __restrict__ logits, int ld, const float* __restrict__ target, int ldt,
+                                                          const float* __restrict__ lse_rows, const float* __restrict__ g, float* __restrict__ dlogits,
+                                                          int ldd, int R, int N) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* row = logits + (size_t)r * ld;
+  const float* tr = target + (size_t)r * ldt;
+  float st = 0.f;
+  for (int j = lane; j < N; j += 64) st += tr[j];
+  st = wave_sum(st);
+  const float lse = lse_rows[r], gr = g[r];
+  for (int j = lane; j < N; j += 64) dlogits[(size_t)r * ldd + j] = gr * (__expf(row[j] - lse) * st - tr[j]);
+  for (int j = N + lane; j < ldd; j += 64) dlogits[(size_t)r * ldd + j] = 0.f;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void igl_blend_kernel(const T* __restrict__ aug, const T* __restrict__ x, const float* __restrict__ wa,
                                                         const float* __restrict__ ba, const float* __restrict__ wo, const float* __restrict__ bo,
@@ -870,6 +909,24 @@ extern "C" int dsrg_ce_rows_fwd(const float* logits, int ld, const int64_t* targ
   if (B == 0) return DSRG_OK;
   hipLaunchKernelGGL(ce_rows_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, ignore_index, lse_rows, loss_rows, N);
   DSRG_LAUNCH_CHECK("dsrg_ce_rows_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_kl_rows_fwd(const float* logits, int ld, const float* target, int ldt, float* lse_rows, float* loss_rows, int R, int N,
+                               void* stream) {
+  DSRG_CHECK(logits && target && lse_rows && loss_rows && R >= 0 && N >= 1 && ld >= N && ldt >= N, "dsrg_kl_rows_fwd: bad arguments");
+  if (R == 0) return DSRG_OK;
+  hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ldt, lse_rows, loss_rows, R, N);
+  DSRG_LAUNCH_CHECK("dsrg_kl_rows_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_kl_rows_bwd(const float* logits, int ld, const float* target, int ldt, const float* lse_rows, const float* grad_rows,
+                               float* dlogits, int ldd, int R, int N, void* stream) {
+  DSRG_CHECK(logits && target && lse_rows && grad_rows && dlogits && R >= 0 && N >= 1 && ld >= N && ldt >= N && ldd >= N, "dsrg_kl_rows_bwd: bad arguments");
+  if (R == 0) return DSRG_OK;
+  hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, target, ldt, lse_rows, grad_rows, dlogits, ldd, R, N);
+  DSRG_LAUNCH_CHECK("dsrg_kl_rows_bwd");
   return DSRG_OK;
 }
 

@@ -120,6 +120,23 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const
   }
 }
 
+// out = (res ? res : 0) + x * keep / (1 - p): nn.Dropout on a hidden state (+ the residual add behind it), the keep decision
+// from the counter hash of (seed, element index) like every other dropout of the library; the backward is the same kernel
+// on dy (res = NULL).
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ out, size_t n4,
+                                                           float p, float inv_keep, unsigned long long seed, const unsigned long long* __restrict__ seed_off) {
+  if (seed_off) seed += *seed_off;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = ld4(x + i * 4);
+    const size_t e = i * 4;
+    a.x *= drop_keep(seed, e, p, inv_keep); a.y *= drop_keep(seed, e + 1, p, inv_keep);
+    a.z *= drop_keep(seed, e + 2, p, inv_keep); a.w *= drop_keep(seed, e + 3, p, inv_keep);
+    if (res) { const float4 r = ld4(res + i * 4); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+    st4(out + i * 4, a);
+  }
+}
+
 // LayerNorm backward.  z = x (+ res); zh = (z - mean) * rstd; y = zh*gamma + beta.
 //   dz = rstd * (g - mean(g) - zh * mean(g*zh)),  g = dy*gamma;   dgamma += sum_rows dy*zh;  dbeta += sum_rows dy
 // One wave per row; a block keeps its dgamma/dbeta partials in registers, then one atomic per column per block.
@@ -355,6 +372,21 @@ extern "C" int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, 
 }
 
 extern "C" int dsrg_layernorm_bwd_blocks(int M) { return M > 0 ? lnb_blocks(M) : 0; }
+
+extern "C" int dsrg_dropout_add(const void* x, const void* residual, void* out, int64_t n, int dtype, float p_drop, uint64_t seed, void* stream) {
+  DSRG_CHECK(x && out && okdt(dtype) && n >= 0 && n % 4 == 0, "dsrg_dropout_add: bad arguments (n must be a multiple of 4)");
+  DSRG_CHECK((((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual) & (dtype == DSRG_F32 ? 15 : 7)) == 0, "dsrg_dropout_add: misaligned pointer");
+  DSRG_CHECK(p_drop >= 0.f && p_drop < 1.f, "dsrg_dropout_add: p_drop=%g out of [0,1)", (double)p_drop);
+  if (n == 0) return DSRG_OK;
+  const size_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+  const float inv_keep = 1.0f / (1.0f - p_drop);
+  const unsigned long long* off = p_drop > 0.f ? dsrg_dropout_offset_ptr() : nullptr;
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((dropout_add_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)residual, (float*)out, n4, p_drop, inv_keep, (unsigned long long)seed, off);
+  else hipLaunchKernelGGL((dropout_add_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)out, n4, p_drop, inv_keep, (unsigned long long)seed, off);
+  DSRG_LAUNCH_CHECK("dsrg_dropout_add");
+  return DSRG_OK;
+}
 
 static int layernorm_bwd_impl(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const void* dy, int lddy,
                               void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, float* partials, int M, int H, float eps,

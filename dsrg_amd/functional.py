@@ -688,6 +688,30 @@ def linear_ln(x, w, b, gamma, beta, eps, residual=None, p_drop=0.0, out=None, au
 
 
 # ----------------------------------------------------------------------------- attention
+class _DropoutAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, p, seed):
+        ctx.cfg = (p, seed, residual is not None)
+        return K.dropout_add(x, residual, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, has_res = ctx.cfg
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        return K.dropout_add(dy, None, p, seed) if ctx.needs_input_grad[0] else None, dy if (has_res and ctx.needs_input_grad[1]) else None, None, None
+
+
+def dropout_add(x, p_drop, residual=None, training=True):
+    """residual + nn.Dropout(p)(x): one HIP kernel forward and one backward, no mask tensor (counter-hash mask, as the
+    attention and LayerNorm dropouts); identity / plain add when not training or p = 0."""
+    if not training or p_drop <= 0.0:
+        return x if residual is None else x + residual
+    seed = dropout_seed()
+    if _needs_grad((x, residual)):
+        return _DropoutAddFn.apply(x, residual, float(p_drop), seed)
+    return K.dropout_add(x, residual, float(p_drop), seed)
+
+
 def dropout_seed():
     """63-bit seed for the in-kernel attention dropout, drawn from torch's CPU generator (follows torch.manual_seed)."""
     return int(torch.empty((), dtype=torch.int64).random_().item())
@@ -1052,6 +1076,32 @@ def cross_entropy_rows(logits, targets, ignore_index=-100):
     if torch.is_grad_enabled() and lg.requires_grad:
         return _CERowsFn.apply(lg, targets.contiguous(), ignore_index)
     return K.ce_rows(lg.detach(), targets.contiguous(), ignore_index)[0]
+
+
+class _KLRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, lse = K.kl_rows(logits, target)
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        return K.kl_rows_bwd(logits, target, lse, g), None
+
+
+def kl_div_rows(logits, target):
+    """F.kl_div(F.log_softmax(logits, -1), target, reduction='none').sum(1) for fp32 [R,N] (the MRC loss, pretrain_cmt.py:215-226):
+    one kernel forward (dsrg_kl_rows_fwd), the gradient recomputed from the logits and the row log-sum-exp in backward."""
+    lg = logits if logits.dtype == torch.float32 else logits.float()
+    lg = lg if lg.stride(-1) == 1 else lg.contiguous()
+    tg = target if (target.dtype == torch.float32 and target.stride(-1) == 1) else target.float().contiguous()
+    if lg.shape[0] == 0:
+        return lg.new_zeros((0,))
+    if torch.is_grad_enabled() and lg.requires_grad:
+        return _KLRowsFn.apply(lg, tg)
+    return K.kl_rows(lg.detach(), tg)[0]
 
 
 def action_tail(nav_logits, targets=None, u=None, ignore_index=-100):

@@ -374,6 +374,22 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     return dq, dk, dv, dsp
 
 
+def dropout_add(x, residual, p_drop, seed):
+    """residual + dropout(x) (residual may be None) with the counter-hash mask of (seed, element index); dsrg_dropout_add"""
+    lib = _lib.load()
+    _dev(x)
+    x = x if x.is_contiguous() else x.contiguous()
+    if residual is not None:
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise _lib.DsrgHipError('dropout_add: residual must have the shape and dtype of x')
+    if x.numel() % 4:
+        raise _lib.DsrgHipError('dropout_add: element count must be a multiple of 4')
+    out = torch.empty_like(x)
+    _lib.check(lib.dsrg_dropout_add(_p(x), _p(residual), _p(out), x.numel(), _dt(x), float(p_drop), int(seed), _stream()), 'dsrg_dropout_add')
+    return out
+
+
 _DROP_OFF = {}
 
 
@@ -767,6 +783,30 @@ def ce_rows(logits, targets, ignore_index=-100):
     loss, lse = torch.empty(B, device=logits.device), torch.empty(B, device=logits.device)
     _lib.check(lib.dsrg_ce_rows_fwd(_p(logits), logits.stride(0), _p(targets), int(ignore_index), _p(lse), _p(loss), B, N, _stream()), 'dsrg_ce_rows_fwd')
     return loss, lse
+
+
+def kl_rows(logits, target):
+    """fp32 logits, target [R,N] -> (loss_rows [R], lse_rows [R]): F.kl_div(log_softmax(logits), target, 'none').sum(1)"""
+    lib = _lib.load()
+    _dev(logits)
+    for t in (logits, target):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise _lib.DsrgHipError('kl_rows: logits and target must be fp32 [R,N] with contiguous rows')
+    if logits.shape != target.shape:
+        raise _lib.DsrgHipError('kl_rows: logits and target must have one shape')
+    R, N = logits.shape
+    loss, lse = torch.empty(R, device=logits.device), torch.empty(R, device=logits.device)
+    _lib.check(lib.dsrg_kl_rows_fwd(_p(logits), logits.stride(0), _p(target), target.stride(0), _p(lse), _p(loss), R, N, _stream()), 'dsrg_kl_rows_fwd')
+    return loss, lse
+
+
+def kl_rows_bwd(logits, target, lse, grad_rows):
+    lib = _lib.load()
+    R, N = logits.shape
+    g = grad_rows if (grad_rows.dtype == torch.float32 and grad_rows.is_contiguous()) else grad_rows.float().contiguous()
+    d = torch.empty(R, N, device=logits.device, dtype=torch.float32)
+    _lib.check(lib.dsrg_kl_rows_bwd(_p(logits), logits.stride(0), _p(target), target.stride(0), _p(lse), _p(g), _p(d), N, R, N, _stream()), 'dsrg_kl_rows_bwd')
+    return d
 
 
 def ce_rows_bwd(logits, targets, lse, grad_rows, ignore_index=-100, out_dtype=torch.float32):

@@ -17,7 +17,6 @@ Two host-side loops of the reference become index tensors consumed on the device
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import functional as Fn
 from ._lib import ACT_GELU, ACT_RELU, MASK_NEG10000
@@ -349,9 +348,9 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             otgt = _memo(b, 'mrc_obj_tgt', lambda: b['vp_obj_probs'][om])
         if not compute_loss:
             return logits, tgt, ologits, otgt
-        loss = F.kl_div(F.log_softmax(logits, -1), tgt, reduction='none').sum(1)
+        loss = Fn.kl_div_rows(logits, tgt)
         if ologits is not None:
-            loss = torch.cat([loss, F.kl_div(F.log_softmax(ologits, -1), otgt, reduction='none').sum(1)], 0)
+            loss = torch.cat([loss, Fn.kl_div_rows(ologits, otgt)], 0)
         return loss
 
     def _og_logits(self, W, b, v, last):   # pretrain_cmt.py:313-321

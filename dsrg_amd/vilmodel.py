@@ -396,8 +396,10 @@ class GlocalTextPathNavCMT(nn.Module):
         """dropout on the attention probabilities of the BERT-style blocks (vilmodel.py:115,150,342), training only"""
         return float(self.config.attention_probs_dropout_prob) if self.training else 0.0
 
-    def _drop(self, x, p):
-        return nn.functional.dropout(x, p, True) if (self.training and p > 0) else x
+    def _drop(self, x, p, residual=None):
+        """residual + nn.Dropout(p)(x) in one HIP kernel (counter-hash mask, recomputed in backward: no mask tensor, and no
+        torch generator inside a captured training step)"""
+        return Fn.dropout_add(x, p, residual, self.training)
 
     def _dense_res_ln(self, W, k_lin, k_ln, h, res, eps):
         """LayerNorm(dropout(dense(h)) + res): BertSelfOutput / BertOutput (vilmodel.py:173-177, 213-217)."""
@@ -476,13 +478,13 @@ class GlocalTextPathNavCMT(nn.Module):
             qkv = Fn.linear(y, W[k + '.qkv.w'], W[k + '.qkv.b'])
             a = Fn.attention_packed(qkv, nh, None, masks, MASK_NEGINF, p_drop=p if self.training else 0.0)       # nn.MultiheadAttention(dropout=hidden_dropout_prob), ops.py:14
             if self.training and p > 0:
-                x = x + self._drop(Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b']), p)
+                x = self._drop(Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b']), p, x)
             else:
                 x = Fn.linear(a, W[k + '.ao.w'], W[k + '.ao.b'], residual=x)
             y = Fn.layernorm(x, W[k + '.n2.g'], W[k + '.n2.b'], 1e-5)
             hdn = self._drop(Fn.linear(y, W[k + '.ff1.w'], W[k + '.ff1.b'], act=ACT_GELU), p)
             if self.training and p > 0:
-                x = x + self._drop(Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b']), p)
+                x = self._drop(Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b']), p, x)
             else:
                 x = Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b'], residual=x)
         return x

@@ -539,6 +539,20 @@ int dsrg_layernorm_bwd_drop(const void* x, int ldx, const void* residual, int ld
                             void* dz, int lddz, void* dzd, int lddzd, float* dgamma, float* dbeta, float* partials, int M, int H,
                             float eps, int in_dtype, int dtype, float p_drop, uint64_t seed, int tag, void* stream);
 
+/* The MRC loss tail, PT/model/pretrain_cmt.py:215-226: F.kl_div(F.log_softmax(logits, -1), target, reduction='none').sum(1)
+ * over fp32 [R, N] rows (N = 1000 view / 1601 object classes): loss_r = sum_c [t > 0] t (log t - x) + lse_r sum_c t; backward
+ * dlogits[r, c] = grad_r (exp(x - lse_r) sum_c t - t), recomputed from the logits and lse_rows (no log-softmax matrix). */
+int dsrg_kl_rows_fwd(const float* logits, int ld, const float* target, int ldt, float* lse_rows, float* loss_rows, int R, int N,
+                     void* stream);
+int dsrg_kl_rows_bwd(const float* logits, int ld, const float* target, int ldt, const float* lse_rows, const float* grad_rows,
+                     float* dlogits, int ldd, int R, int N, void* stream);
+
+/* out = (residual ? residual : 0) + x * keep / (1 - p_drop) over n contiguous elements (n % 4 == 0): nn.Dropout on a hidden
+ * state with the residual add behind it - the embedding dropout (FT/vilmodel.py:89-90) and the pre-norm panorama encoder's
+ * `src + dropout(...)` (models/transformer.py:153-160).  Keep decision of element i = the library's counter hash of (seed, i)
+ * (+ the dropout offset word), so the backward is the same call on dy with residual = NULL and no mask tensor exists. */
+int dsrg_dropout_add(const void* x, const void* residual, void* out, int64_t n, int dtype, float p_drop, uint64_t seed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

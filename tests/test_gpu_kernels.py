@@ -1141,3 +1141,54 @@ def test_dropout_seed_offset_word(K, dtype):
     assert not torch.equal(plain[0], want[0]) and not torch.equal(plain[4], want[4])
     for a, c in zip(run(seed), plain):         # cleared: the seed alone again
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_add(K, dtype):
+    """functional.dropout_add (dsrg_dropout_add): residual + dropout(x) against torch with the SAME keep mask (numpy
+    restatement of the counter hash), forward and both gradients; identity when not training."""
+    from dsrg_amd import functional as Fn
+    B, N, H, p, seed = 3, 37, 768, 0.1, 987654321
+    x0, r0 = _r(B, N, H, dtype=dtype), _r(B, N, H, seed=1, dtype=dtype)
+    go = _r(B, N, H, seed=2, dtype=dtype)
+    keep = _keep_mask(seed, 1, 1, B * N, H, p)[0, 0].reshape(B, N, H).float() / (1 - p)
+    assert 0.85 < (keep > 0).float().mean().item() < 0.95
+    orig = Fn.dropout_seed
+    Fn.dropout_seed = lambda: seed
+    try:
+        for with_res in (True, False):
+            x, r = x0.clone().requires_grad_(True), (r0.clone().requires_grad_(True) if with_res else None)
+            y = Fn.dropout_add(x, p, r, True)
+            y.backward(go)
+            want = x0.float() * keep + (r0.float() if with_res else 0.0)
+            tol = 1e-6 if dtype == torch.float32 else 2e-2
+            assert (y.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+            assert (x.grad.float() - go.float() * keep).abs().max().item() <= tol * max(1.0, go.float().abs().max().item())
+            if with_res:
+                assert torch.equal(r.grad, go)
+        with torch.no_grad():
+            assert torch.equal(Fn.dropout_add(x0, p, None, False), x0)
+            assert torch.equal(Fn.dropout_add(x0, p, r0, False), x0 + r0)
+    finally:
+        Fn.dropout_seed = orig
+
+
+@pytest.mark.parametrize('R,N', [(131, 1000), (5, 1601), (1, 7)])
+def test_kl_div_rows(K, R, N):
+    """functional.kl_div_rows (dsrg_kl_rows_fwd / _bwd) against F.kl_div(F.log_softmax(x), t, 'none').sum(1) and its autograd;
+    targets with exact zeros (xlogy(0, 0) = 0) and rows that do not sum to one."""
+    from dsrg_amd import functional as Fn
+    torch.manual_seed(R + N)
+    x0 = torch.randn(R, N, device='cuda') * 3
+    t = torch.softmax(torch.randn(R, N, device='cuda') * 2, -1)
+    t[:, ::3] = 0.0
+    t[0] *= 0.5
+    g = torch.rand(R, device='cuda') + 0.1
+    a, b = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    want = torch.nn.functional.kl_div(torch.log_softmax(a, -1), t, reduction='none').sum(1)
+    got = Fn.kl_div_rows(b, t)
+    assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    (want * g).sum().backward(); (got * g).sum().backward()
+    assert (a.grad - b.grad).abs().max().item() <= 2e-6
+    with torch.no_grad():
+        assert torch.equal(Fn.kl_div_rows(x0, t), got.detach())
