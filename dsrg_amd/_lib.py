@@ -81,6 +81,7 @@ SIGNATURES = {
     'dsrg_set_dropout_offset': (C.c_int, [_P]),
     'dsrg_kl_rows_fwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _P]),
     'dsrg_kl_rows_bwd': (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    'dsrg_sum_slabs': (C.c_int, [_P, _I, _L, _P, _L, _I, _P]),
     'dsrg_dropout_add': (C.c_int, [_P, _P, _P, _L, _I, _F, C.c_uint64, _P]),
     'dsrg_opt_chunk': (C.c_int, []),
     'dsrg_grad_sumsq': (C.c_int, [_P, _P, _I, _P, _P]),

@@ -112,7 +112,9 @@ template <typename T, typename OutT, int BM, int BN, int NST, int FUSE = 0, int 
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const GemmArgs args) {
   GEMM_STAMP(0);
   constexpr bool TA = (TRANS & 1) != 0, TW = (TRANS & 2) != 0;
-  static_assert(TRANS == 0 || (BM == 64 && BN == 64 && sizeof(T) == 2 && FUSE == 0), "transposed operands: bf16, 64x64 tile");
+  // A transposed operand of a tile wider than 64 is staged as BM/64 (BN/64) blocks of 64 contraction rows x 64 columns, each
+  // with the 64x64 tile's own layout, one after the other (a "row" of the stage below is block * 64 + contraction row).
+  static_assert(TRANS == 0 || (BM % 64 == 0 && BN % 64 == 0 && sizeof(T) == 2 && FUSE == 0), "transposed operands: bf16, tiles of 64-column blocks");
   constexpr int PER16 = Elem<T>::PER16;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int NWAVES = WAVES_M * WAVES_N, THREADS = 64 * NWAVES;
@@ -243,15 +245,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
     const int row = (i * NWAVES + wave) * 8 + (lane >> 3);  // row of the stage
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     if (i < LPA) {
-      if constexpr (TA) {     // row = contraction row of the stage; the 16-byte chunk holds 8 output rows (clamped whole: M % 8 == 0)
-        const int col = min(m0 + (((lane & 7) ^ swt(row)) << 3), M - 8);
-        voff[i] = (unsigned)row * (unsigned)(P.lda * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
+      if constexpr (TA) {     // row = (block, contraction row) of the stage; the 16-byte chunk holds 8 output rows (clamped whole: M % 8 == 0)
+        const int kr = row & 63, blk = row >> 6;
+        const int col = min(m0 + blk * 64 + (((lane & 7) ^ swt(kr)) << 3), M - 8);
+        voff[i] = (unsigned)kr * (unsigned)(P.lda * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
       } else voff[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)(P.lda * (int)sizeof(T)) + chunk * 16;
     } else {
       if constexpr (TW) {
-        const int rw = row - BM;
-        const int col = min(n0 + (((lane & 7) ^ swt(rw)) << 3), N - 8);
-        voff[i] = (unsigned)rw * (unsigned)(P.ldw * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
+        const int rw = row - BM, kr = rw & 63, blk = rw >> 6;
+        const int col = min(n0 + blk * 64 + (((lane & 7) ^ swt(kr)) << 3), N - 8);
+        voff[i] = (unsigned)kr * (unsigned)(P.ldw * (int)sizeof(T)) + (unsigned)col * (unsigned)sizeof(T);
       } else voff[i] = (unsigned)min(n0 + row - BM, N - 1) * (unsigned)(P.ldw * (int)sizeof(T)) + chunk * 16;
     }
   }
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
       typedef short v4s __attribute__((ext_vector_type(4)));
       const int krow = 32 * kk + 8 * q + (r16 >> 2);
       const int c = (col16 >> 3) + ((r16 & 3) >> 1);
-      const char* p = tile + krow * ROWB + ((c ^ swt(krow)) << 4) + ((r16 & 1) << 3);     // rows +4: same swizzle, +512 bytes
+      const char* p = tile + (col16 >> 6) * (64 * ROWB) + krow * ROWB + (((c & 7) ^ swt(krow)) << 4) + ((r16 & 1) << 3);     // rows +4: same swizzle, +512 bytes
       const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
       const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * ROWB));
       const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(const G
 #pragma unroll
         for (int i = 0; i < LPA; ++i) {
           const int row = (i * NWAVES + wave) * 8 + (lane >> 3);
-          if (row >= krem) *reinterpret_cast<uint4*>(sa + row * ROWB + ((lane & 7) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+          if ((row & (BK - 1)) >= krem) *reinterpret_cast<uint4*>(sa + row * ROWB + ((lane & 7) << 4)) = make_uint4(0u, 0u, 0u, 0u);
         }
       }
     }
@@ -848,7 +851,26 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
     minK = a.p[i].K < minK ? a.p[i].K : minK;
   }
-  // LayerNorm-fusion kinds (FUSE_A: 64x64 and 128x128x2; FUSE_RS: 64x64 and 128x64x4) and transposed operands (64x64 only)
+  // wgrad launches (every problem dW = dY^T.X on operands as they lie, trans = 3; bf16) can run 128-row tiles (a transposed
+  // operand staged as 64-column blocks): DSRG_GEMM_WGRAD = "BMxBNxNST:mintiles" (128x128x2 | 128x64x3).  OFF by default -
+  // measured on the pre-training step (one box, ms per step): 64x64 11.71 | 128x64x3 from 150 tiles 11.67 | 128x128x2 from 100
+  // tiles 12.00 | from 30 tiles 12.37: dW of the packed QKV / FFN weights is only 108 / 144 tiles of 128x128, and as with the
+  // forward launches a half-empty chip of large tiles loses to 4 rounds of small ones.
+  {
+    bool all_t3 = a.nprob > 0 && bf16;
+    for (int i = 0; i < a.nprob; ++i) all_t3 = all_t3 && a.p[i].trans == 3;
+    if (all_t3) {
+      static const char* wg_env = getenv("DSRG_GEMM_WGRAD");
+      const char* e = wg_env ? wg_env : "0";
+      int tbm = 0, tbn = 0, tnst = 0, tmin = 0;
+      if (sscanf(e, "%dx%dx%d:%d", &tbm, &tbn, &tnst, &tmin) == 4 &&
+          ((tbm == 128 && tbn == 128 && tnst == 2) || (tbm == 128 && tbn == 64 && tnst == 3)) && count_tiles(a, tbm, tbn) >= tmin) {
+        bm = tbm; bn = tbn; nst = tnst;
+        return count_tiles(a, bm, bn);
+      }
+    }
+  }
+  // LayerNorm-fusion kinds (FUSE_A: 64x64 and 128x128x2; FUSE_RS: 64x64 and 128x64x4) and transposed operands (64x64, wgrad above)
   bool fuse_a = false, fuse_rs = false, only64 = false;
   for (int i = 0; i < a.nprob; ++i) {
     fuse_a = fuse_a || a.p[i].a_stats;
@@ -929,9 +951,13 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
   bool fuse_a = false, fuse_rs = false;
   for (int i = 0; i < a.nprob; ++i) { fuse_a = fuse_a || a.p[i].a_stats; fuse_rs = fuse_rs || a.p[i].r_stats || a.p[i].stats_out; }
   if (a.p[0].trans) {      // backward GEMMs on operands as they lie (no transposed copies); bf16 checked by the entry
-    DSRG_CHECK(bm == 64 && bn == 64 && (nst == 2 || nst == 3), "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3) only, not %dx%dx%d", bm, bn, nst);
+    const bool wg_tile = a.p[0].trans == 3 && ((bm == 128 && bn == 128 && nst == 2) || (bm == 128 && bn == 64 && nst == 3));
+    DSRG_CHECK((bm == 64 && bn == 64 && (nst == 2 || nst == 3)) || wg_tile,
+               "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3) and, trans = 3 only, 128x128x2 / 128x64x3, not %dx%dx%d", bm, bn, nst);
     if constexpr (sizeof(T) == 2) {
       const int tr = a.p[0].trans;
+      if (tr == 3 && bm == 128 && bn == 128) return launch<T, OutT, 128, 128, 2, false, 2, 2, 3>(a, tiles, s);
+      if (tr == 3 && bm == 128 && bn == 64) return launch<T, OutT, 128, 64, 3, false, 2, 2, 3>(a, tiles, s);
 #define DSRG_TRANS_CASE(TR_, NST_) if (tr == TR_ && nst == NST_) return launch<T, OutT, 64, 64, NST_, false, 2, 2, TR_>(a, tiles, s)
       DSRG_TRANS_CASE(1, 2); DSRG_TRANS_CASE(1, 3); DSRG_TRANS_CASE(2, 2); DSRG_TRANS_CASE(2, 3); DSRG_TRANS_CASE(3, 2); DSRG_TRANS_CASE(3, 3);
 #undef DSRG_TRANS_CASE
@@ -1002,8 +1028,9 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
     DSRG_CHECK(p.res_act >= DSRG_ACT_NONE && p.res_act <= DSRG_ACT_TANH && (p.res_act == DSRG_ACT_NONE || (p.residual && !p.r_stats)),
                "dsrg_gemm_nt: problem %d: res_act=%d needs a residual (the pre-activation) and no r_stats", i, p.res_act);
     DSRG_CHECK(p.trans >= 0 && p.trans <= 3 && p.trans == problems[0].trans, "dsrg_gemm_nt: problem %d: trans=%d must be 0..3 and the same for the whole group", i, p.trans);
-    DSRG_CHECK(p.trans == 0 || (dtype == DSRG_BF16 && !p.a_stats && !p.r_stats && !p.stats_out && fbm <= 0),
-               "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion or a pinned tile", i);
+    DSRG_CHECK(p.trans == 0 || (dtype == DSRG_BF16 && !p.a_stats && !p.r_stats && !p.stats_out &&
+                                (fbm <= 0 || (p.trans == 3 && fbm == 128 && (fbn == 128 || fbn == 64)))),
+               "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion; a pinned tile only with trans = 3 (128x128x2, 128x64x3)", i);
     const bool ta = (p.trans & 1) != 0, tw = (p.trans & 2) != 0;
     // a transposed operand is [K, M] / [K, N]: whole 16-byte chunks of 8 output rows / columns
     DSRG_CHECK(p.lda % al == 0 && p.lda >= (ta ? p.M : p.K) && (!ta || (p.M % 8 == 0 && p.M >= 8)),

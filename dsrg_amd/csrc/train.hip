@@ -120,6 +120,27 @@ __global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ z, const
   }
 }
 
+// out[i] = sum_s in[s * stride + i] (fixed order): the fix-up of a K-split wgrad whose S problems left fp32 partial tiles
+template <typename OutT>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ in, int S, size_t stride, OutT* __restrict__ out, size_t n) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = *reinterpret_cast<const float4*>(in + i * 4);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(in + (size_t)s * stride + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    st4(out + i * 4, a);
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      float a = in[i];
+      for (int s = 1; s < S; ++s) a += in[(size_t)s * stride + i];
+      Elem<OutT>::st(out + i, a);
+    }
+  }
+}
+
 // out = (res ? res : 0) + x * keep / (1 - p): nn.Dropout on a hidden state (+ the residual add behind it), the keep decision
 // from the counter hash of (seed, element index) like every other dropout of the library; the backward is the same kernel
 // on dy (res = NULL).
@@ -372,6 +393,18 @@ extern "C" int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, 
 }
 
 extern "C" int dsrg_layernorm_bwd_blocks(int M) { return M > 0 ? lnb_blocks(M) : 0; }
+
+extern "C" int dsrg_sum_slabs(const float* in, int S, int64_t slab_stride, void* out, int64_t n, int out_dtype, void* stream) {
+  DSRG_CHECK(in && out && okdt(out_dtype) && S >= 1 && n >= 0 && slab_stride >= n && slab_stride % 4 == 0, "dsrg_sum_slabs: bad arguments (slab_stride %% 4 == 0, >= n)");
+  DSRG_CHECK((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & (out_dtype == DSRG_F32 ? 15 : 7)) == 0, "dsrg_sum_slabs: misaligned pointer");
+  if (n == 0) return DSRG_OK;
+  const size_t n4 = (size_t)n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256 < 1 ? 1 : (n4 + 255) / 256);
+  if (out_dtype == DSRG_F32) hipLaunchKernelGGL((sum_slabs_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, S, (size_t)slab_stride, (float*)out, (size_t)n);
+  else hipLaunchKernelGGL((sum_slabs_kernel<bf16_t>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, S, (size_t)slab_stride, (bf16_t*)out, (size_t)n);
+  DSRG_LAUNCH_CHECK("dsrg_sum_slabs");
+  return DSRG_OK;
+}
 
 extern "C" int dsrg_dropout_add(const void* x, const void* residual, void* out, int64_t n, int dtype, float p_drop, uint64_t seed, void* stream) {
   DSRG_CHECK(x && out && okdt(dtype) && n >= 0 && n % 4 == 0, "dsrg_dropout_add: bad arguments (n must be a multiple of 4)");

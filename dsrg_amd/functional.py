@@ -230,6 +230,7 @@ def _gemm_grads(items):
     dball = K.zeros_f32((nb,), items[0][2].device) if nb else None
     dxp, dwp, dbs, o = [], [], [], 0
     fdx, fdw, fdb = [], [], []                 # problems on operands as they lie (fdb: where a wgrad's column sums of dY go)
+    sdw = []                                   # wgrads that run K-split (few output tiles, thousands of rows)
     fra, tra = [], []                          # res_act of the dgrad problems (fast / transposed-copy path)
     tr = []                                    # every transpose of this call: one grouped launch
     slots = []                                 # per item: where its dx / dw come from
@@ -251,7 +252,9 @@ def _gemm_grads(items):
                 dyp = dy if Np == N else torch.nn.functional.pad(dy, (0, Np - N))
                 sx = ('t', len(dxp)); dxp.append([dyp, len(tr), None, zr]); tra.append(ract); tr.append((w, None))   # [M,Np] x [K,Np]^T
         if ndw:
-            if lies and _lies_ok(x):
+            if lies and _lies_ok(x) and _wgrad_splits(M, N, Kd) > 1:
+                sw = ('s', len(sdw)); sdw.append((dy, x, db))     # a small dW over many rows: K-split, below
+            elif lies and _lies_ok(x):
                 sw = ('f', len(fdw)); fdw.append((dy, x, None, None)); fdb.append(db)    # dY [M,N] = [K',M'], X [M,K] = [K',N']
             else:
                 sw = ('t', len(dwp)); dwp.append([len(tr), len(tr) + 1, None, None]); tr += [(dy, db), (x, None)]   # [N,Mp] x [K,Mp]^T
@@ -259,7 +262,7 @@ def _gemm_grads(items):
             K.colsum(dy, out=db)
         dbs.append(db)
         slots.append((sx, sw))
-    res = {'f': [None, None], 't': [None, None]}
+    res = {'f': [None, None], 't': [None, None], 's': [None, [_wgrad_split(dy, x, db) for dy, x, db in sdw]]}
     if fdx:
         res['f'][0] = [K.gemm(fdx[i:i + _lib.MAX_GROUPS], trans=2, res_acts=fra[i:i + _lib.MAX_GROUPS]) for i in range(0, len(fdx), _lib.MAX_GROUPS)]
         res['f'][0] = [t for g in res['f'][0] for t in g]
@@ -279,6 +282,38 @@ def _gemm_grads(items):
     outx = [None if sx is None else res[sx[0]][0][sx[1]] for sx, _ in slots]
     outw = [None if sw is None else res[sw[0]][1][sw[1]] for _, sw in slots]
     return outx, outw, dbs
+
+
+WGRAD_SPLIT = __import__('os').environ.get('DSRG_WGRAD_SPLIT', '1') == '1'
+
+
+def _wgrad_splits(M, N, Kd):
+    """K-split factor of dW [N, Kd] = dY^T.X over M token rows: 1 unless the launch would leave most of the chip idle for a
+    long time - fewer than 128 tiles of 64x64 and at least 4096 rows (the object-token encoder's weights: 4-96 tiles, 14,796
+    rows, 80-96 us per launch on 4-96 workgroups, profiles/r03n_c4_pmc_fetch.csv).  Each slice gets >= 1024 rows."""
+    if not WGRAD_SPLIT or M < 4096 or N % 64 or Kd % 4:
+        return 1
+    tiles = ((N + 63) // 64) * ((Kd + 63) // 64)
+    if tiles >= 128:
+        return 1
+    return max(1, min(_lib.MAX_GROUPS, M // 1024))
+
+
+def _wgrad_split(dy, x, db):
+    """dW = dY^T.X as S problems of one grouped launch over row slices (fp32 partial tiles) + one dsrg_sum_slabs; the bias
+    gradient (column sums of dY) the same way."""
+    M, N = dy.shape
+    Kd = x.shape[1]
+    S = _wgrad_splits(M, N, Kd)
+    step = ((M + S - 1) // S + 63) // 64 * 64
+    cuts = [(r, min(M, r + step)) for r in range(0, M, step)]
+    part = torch.empty(len(cuts), N, Kd, device=dy.device, dtype=torch.float32)
+    dbp = torch.empty(len(cuts), N, device=dy.device, dtype=torch.float32) if db is not None else None
+    K.gemm([(dy[a:b], x[a:b], None, None) for a, b in cuts], out_f32=True, trans=3, outs=[part[i] for i in range(len(cuts))],
+           colsums=None if db is None else [dbp[i] for i in range(len(cuts))])
+    if db is not None:
+        K.sum_slabs(dbp, out=db)
+    return K.sum_slabs(part, out_dtype=dy.dtype)
 
 
 class _LinearFn(torch.autograd.Function):

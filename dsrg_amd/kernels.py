@@ -374,6 +374,21 @@ def attention_bwd(q, k, v, o, do, lse, nh, kmask, mask_mode, dists, sprel_w, spr
     return dq, dk, dv, dsp
 
 
+def sum_slabs(part, out=None, out_dtype=torch.float32):
+    """part fp32 [S, ...] contiguous -> sum over dim 0 in slab order (dsrg_sum_slabs); out: optional contiguous target"""
+    lib = _lib.load()
+    _dev(part)
+    if part.dtype != torch.float32 or not part.is_contiguous():
+        raise _lib.DsrgHipError('sum_slabs: fp32 contiguous input')
+    S, n = part.shape[0], part[0].numel()
+    if out is None:
+        out = torch.empty(part.shape[1:], device=part.device, dtype=out_dtype)
+    if out.numel() != n or not out.is_contiguous() or n % 4:
+        raise _lib.DsrgHipError('sum_slabs: out must be contiguous with the slab size (a multiple of 4 elements)')
+    _lib.check(lib.dsrg_sum_slabs(_p(part), S, n, _p(out), n, _dt(out), _stream()), 'dsrg_sum_slabs')
+    return out
+
+
 def dropout_add(x, residual, p_drop, seed):
     """residual + dropout(x) (residual may be None) with the counter-hash mask of (seed, element index); dsrg_dropout_add"""
     lib = _lib.load()

@@ -547,6 +547,12 @@ int dsrg_kl_rows_fwd(const float* logits, int ld, const float* target, int ldt, 
 int dsrg_kl_rows_bwd(const float* logits, int ld, const float* target, int ldt, const float* lse_rows, const float* grad_rows,
                      float* dlogits, int ldd, int R, int N, void* stream);
 
+/* out[i] = sum_{s < S} in[s * slab_stride + i], i < n, summed in slab order; out is fp32 or bf16.  The fix-up of a K-split
+ * weight gradient: dW = dY^T.X of a small weight over many token rows (the object-token encoder: 128 x 128 ... 3072 x 128
+ * outputs over 14,796 rows) runs as S problems of ONE grouped dsrg_gemm_nt launch (trans = 3, fp32 outputs), each over a
+ * slice of the rows; no counterpart in the reference (autograd's `grad_output.t().mm(input)`). */
+int dsrg_sum_slabs(const float* in, int S, int64_t slab_stride, void* out, int64_t n, int out_dtype, void* stream);
+
 /* out = (residual ? residual : 0) + x * keep / (1 - p_drop) over n contiguous elements (n % 4 == 0): nn.Dropout on a hidden
  * state with the residual add behind it - the embedding dropout (FT/vilmodel.py:89-90) and the pre-norm panorama encoder's
  * `src + dropout(...)` (models/transformer.py:153-160).  Keep decision of element i = the library's counter hash of (seed, i)

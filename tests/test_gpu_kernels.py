@@ -122,6 +122,12 @@ def test_gemm_wgrad_any_rows_and_column_sums(K, M, N, K_):
     bigx = torch.full((K_ + 64, N), float('nan'), device=dy.device, dtype=dtype); bigx[:K_] = x
     out2 = K.gemm([(big[:K_], bigx[:K_], None, None)], trans=3)[0]
     assert torch.equal(out2, base)
+    # round 3: the wide wgrad tiles (a transposed operand staged as 64-column blocks) - same K order, same MFMA: bit-exact too
+    for tile in ((128, 128, 2), (128, 64, 3)):
+        db2 = torch.full((M,), 7.0, device=dy.device)
+        o = K.gemm([(big[:K_], bigx[:K_], None, None)], trans=3, colsums=[db2], tile=tile)[0]
+        assert torch.equal(o, base), (tile, (o.float() - base.float()).abs().max().item())
+        assert torch.equal(db2, db), tile
 
 
 def test_gemm_transposed_operands_rejects_bad_shapes(K):
@@ -1192,3 +1198,31 @@ def test_kl_div_rows(K, R, N):
     assert (a.grad - b.grad).abs().max().item() <= 2e-6
     with torch.no_grad():
         assert torch.equal(Fn.kl_div_rows(x0, t), got.detach())
+
+
+def test_wgrad_k_split_matches_single_launch(K):
+    """functional._gemm_grads: dW of a small weight over thousands of rows runs K-split (S row slices as problems of one
+    grouped trans = 3 launch with fp32 partial tiles + dsrg_sum_slabs); against the unsplit launch (fp32 accumulation order
+    differs, so a bf16 ulp at most) and torch in fp32; the bias gradient too."""
+    from dsrg_amd import functional as Fn
+    for M, N, Kd in ((14796, 128, 128), (5000, 384, 128), (4100, 3072, 128 // 2 * 2)):
+        dy, x = _r(M, N, dtype=torch.bfloat16), _r(M, Kd, seed=1, dtype=torch.bfloat16)
+        w = _r(N, Kd, seed=2, dtype=torch.bfloat16)
+        assert Fn._wgrad_splits(M, N, Kd) > 1
+        _, dws, dbs = Fn._gemm_grads([(x, w, dy, False, True, True)])
+        Fn.WGRAD_SPLIT = False
+        try:
+            _, dw1, db1 = Fn._gemm_grads([(x, w, dy, False, True, True)])
+        finally:
+            Fn.WGRAD_SPLIT = True
+        ref = dy.float().T @ x.float()
+        tol = 1e-2 * ref.abs().max().item()
+        assert (dws[0].float() - ref).abs().max().item() <= tol
+        assert (dws[0].float() - dw1[0].float()).abs().max().item() <= 2 * tol / 1e-2 * 2 ** -8
+        refb = dy.float().sum(0)
+        assert (dbs[0] - refb).abs().max().item() <= 1e-4 * max(1.0, refb.abs().max().item()) * math.sqrt(M)
+        assert (dbs[0] - db1[0]).abs().max().item() <= 1e-3 * max(1.0, refb.abs().max().item())
+    assert Fn._wgrad_splits(1920, 768, 768) == 1 and Fn._wgrad_splits(14796, 3072, 768) == 1
+    # sum_slabs on its own, odd tail
+    p = torch.randn(5, 1000, device='cuda')
+    assert torch.allclose(K.sum_slabs(p), p.sum(0), atol=1e-5)
