@@ -103,6 +103,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_step_kernel(const dsrg_opt_
   const float* g = reinterpret_cast<const float*>(t.g) + base;
   float* m = t.m + base;
   float* v = t.v + base;
+  bf16_t* pk = t.pack ? reinterpret_cast<bf16_t*>(t.pack) + base : nullptr;      // compute-dtype copy of the parameter (the next forward's operand)
   if (t.vec_ok && n == OPT_CHUNK) {
     float4 pv[OPT_VEC], gv[OPT_VEC], mv[OPT_VEC], vv[OPT_VEC];
 #pragma unroll
@@ -119,12 +120,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_step_kernel(const dsrg_opt_
       adamw_one(pv[i].z, gv[i].z, mv[i].z, vv[i].z, coef, c, step_size, decay);
       adamw_one(pv[i].w, gv[i].w, mv[i].w, vv[i].w, coef, c, step_size, decay);
       reinterpret_cast<float4*>(p)[j] = pv[i]; reinterpret_cast<float4*>(m)[j] = mv[i]; reinterpret_cast<float4*>(v)[j] = vv[i];
+      if (pk) st4(pk + 4 * j, pv[i]);
     }
   } else {
     for (long long i = threadIdx.x; i < n; i += OPT_THREADS) {
       float pp = p[i], mm = m[i], vv = v[i];
       adamw_one(pp, g[i], mm, vv, coef, c, step_size, decay);
       p[i] = pp; m[i] = mm; v[i] = vv;
+      if (pk) pk[i] = f2bf(pp);
     }
   }
 }

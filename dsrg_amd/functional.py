@@ -63,12 +63,29 @@ class _PackFn(torch.autograd.Function):
             # the plan aliases the parameters' storage: a parameter whose storage was swapped outside Module._apply
             # (`p.data = ...`, vector_to_parameters, an EMA swap, load_state_dict(assign=True)) invalidates it
             if plan is None or plan['ptrs'] != [t.data_ptr() for t in srcs]:
+                managed = spec.managed
                 plan = spec.plan = _pack_plan(spec, srcs)
-            flats = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
-            parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
-            for (dd, sd), (pidx, dets) in plan['copies'].items():
-                pp = parts[dd]
-                torch._foreach_copy_([pp[j] for j in pidx], dets)
+                if managed is not None:            # the parameters moved: the optimizer's destinations moved with the buffers
+                    managed.attach_packs(managed._pack_specs)
+            if spec.managed is None:
+                flats = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
+                parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
+                for (dd, sd), (pidx, dets) in plan['copies'].items():
+                    pp = parts[dd]
+                    torch._foreach_copy_([pp[j] for j in pidx], dets)
+            else:
+                # optimizer-managed pack (manage_pack): persistent buffers; the optimizer's update kernel writes every changed
+                # parameter's bf16 copy, so the cast pass runs only when something else touched the parameters (version
+                # counters) and for the sources the optimizer does not cover
+                flats = plan['pflats']
+                parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
+                vers = tuple(t._version for t in srcs)
+                full = plan.get('synced') != vers
+                for (dd, sd), (pidx, dets) in plan['copies'].items():
+                    keep = range(len(pidx)) if full else plan['unmanaged'].get((dd, sd), ())
+                    if len(keep):
+                        torch._foreach_copy_([parts[dd][pidx[i]] for i in keep], [dets[i] for i in keep])
+                plan['synced'] = vers
             outs = [torch.as_strided(flats[d], shape, strides, off) for d, shape, strides, off in plan['outs']]
             if isinstance(ctx, torch.autograd.function.FunctionCtx):
                 ctx.set_materialize_grads(False)
@@ -126,6 +143,43 @@ class _PackFn(torch.autograd.Function):
 class _Spec(tuple):
     """the packer's (dtype, source indices) groups; a tuple subclass so that the static part of the pack (`plan`) can ride on it"""
     plan = None
+    managed = None          # the optimizer that keeps this pack's buffers current (manage_pack)
+
+
+def manage_pack(spec, optimizer):
+    """Hand a pack's bf16 copies over to `optimizer` (dsrg_amd.optim.AdamW.attach_packs) - or, with None, take them back.
+    Gives the pack persistent buffers and returns [(parameter address, address of its bf16 copy)] for every fp32 source that
+    is a plain cast into a bf16 buffer; the optimizer's update kernel then writes those copies and _PackFn.forward skips them.
+    Needs a plan, i.e. one forward in grad mode must have run."""
+    plan = spec.plan
+    if plan is None:
+        raise RuntimeError('manage_pack: this pack has not run yet (one forward first)')
+    if optimizer is None:
+        spec.managed = None
+        plan.pop('pflats', None); plan.pop('synced', None); plan.pop('unmanaged', None)
+        return []
+    if 'pflats' not in plan:
+        plan['pflats'] = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
+    plan['synced'] = None
+    pairs, unmanaged, seen = [], {}, set()
+    owned = {p.data_ptr() for p in optimizer._index}
+    for (dd, sd), (pidx, dets) in plan['copies'].items():
+        offs, o = [], 0
+        for n in plan['sizes'][dd]:
+            offs.append(o); o += n
+        base = plan['pflats'][dd].data_ptr()
+        es = plan['pflats'][dd].element_size()
+        left = []
+        for i, (j, det) in enumerate(zip(pidx, dets)):
+            sp = det.data_ptr()
+            if dd == torch.bfloat16 and sd == torch.float32 and sp in owned and sp not in optimizer._pack_dst and sp not in seen:
+                pairs.append((sp, base + offs[j] * es)); seen.add(sp)
+            else:
+                left.append(i)
+        unmanaged[(dd, sd)] = left
+    plan['unmanaged'] = unmanaged
+    spec.managed = optimizer
+    return pairs
 
 
 def _pack_plan(spec, srcs):

@@ -22,7 +22,7 @@ from . import _lib
 from .kernels import _p, _stream
 
 _TENSOR = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('numel', '<i8'), ('group', '<i4'), ('step_idx', '<i4'),
-                    ('vec_ok', '<i4'), ('reserved_', '<i4')])          # = dsrg_opt_tensor_t (include/dsrg_hip.h), 56 bytes
+                    ('vec_ok', '<i4'), ('reserved_', '<i4'), ('pack', '<u8')])          # = dsrg_opt_tensor_t (include/dsrg_hip.h), 64 bytes
 
 
 class _Plan:
@@ -47,6 +47,7 @@ class AdamW(torch.optim.Optimizer):
         self._dev = None
         self._plans = []                # most recent first; a plan is keyed by the (parameter, gradient) addresses it was built for
         self._captured = []
+        self._pack_dst, self._pack_gen, self._pack_specs = {}, 0, []      # attach_packs()
         self._pending = None            # plan whose prepare launch (clip_grad_norm) already ran for the coming step()
         self.grad_scale = 1.0           # multiplies every gradient where it is read (1 / world size after a summing all-reduce)
 
@@ -86,7 +87,7 @@ class AdamW(torch.optim.Optimizer):
             return None
         self._ensure_device()
         capturing = torch.cuda.is_current_stream_capturing()
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for _, p in ents)
+        key = (self._pack_gen,) + tuple((p.data_ptr(), p.grad.data_ptr()) for _, p in ents)
         for pl in self._plans + self._captured:
             if pl.key == key:
                 if pl.host is not None and not capturing:
@@ -110,7 +111,8 @@ class AdamW(torch.optim.Optimizer):
                 st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] = self._steps[self._index[p]]
             ptrs = (p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr())
-            tab[i] = ptrs + (p.numel(), gi, self._index[p], int(all(a % 16 == 0 for a in ptrs)), 0)
+            pack = self._pack_dst.get(p.data_ptr(), 0)
+            tab[i] = ptrs + (p.numel(), gi, self._index[p], int(all(a % 16 == 0 for a in ptrs) and pack % 8 == 0), 0, pack)
         nch = (tab['numel'] + self._chunk - 1) // self._chunk
         starts = np.cumsum(nch) - nch
         blocks = np.empty((int(nch.sum()), 2), np.int32)
@@ -120,7 +122,7 @@ class AdamW(torch.optim.Optimizer):
         pl = _Plan()
         pl.key, pl.consts, pl.n_tensors, pl.n_blocks = key, consts, len(ents), blocks.shape[0]
         pl.dev = torch.empty(raw.shape[0], dtype=torch.uint8, device=self._dev)
-        pl.table, pl.blocks = pl.dev.data_ptr(), pl.dev.data_ptr() + tab.nbytes           # 56-byte entries: the block table stays 8-byte aligned
+        pl.table, pl.blocks = pl.dev.data_ptr(), pl.dev.data_ptr() + tab.nbytes           # 64-byte entries: the block table stays 8-byte aligned
         pl.partials = torch.empty(pl.n_blocks, dtype=torch.float32, device=self._dev)
         if capturing:
             # a memcpy node that re-reads its pinned source on every replay: the source is a region of the arena that is
@@ -149,6 +151,26 @@ class AdamW(torch.optim.Optimizer):
         _lib.check(lib.dsrg_adamw_prepare(_p(pl.partials), n_part, float(max_norm or 0.0), float(self.grad_scale), _p(self._norm),
                                           pl.table, pl.n_tensors, _p(self._steps), _stream()), 'dsrg_adamw_prepare')
         self._pending = pl
+
+    # ------------------------------------------------------------------ packed-weight hand-over
+    def attach_packs(self, specs):
+        """specs: the model's weight packs (functional._Spec objects that carry a plan, see functional.manage_pack).  From now
+        on step() also writes every updated parameter, rounded to bf16, into its place in the packs' persistent buffers, and
+        the packs' forward skips its cast pass over those parameters (0.4 ms per pre-training step).  Contract: while
+        attached, parameters change only through this optimizer (load_state_dict / `.data =` are detected and re-synced)."""
+        from . import functional as Fn
+        self._pack_dst, self._pack_specs = {}, list(specs)
+        for spec in self._pack_specs:
+            for src_ptr, dst_ptr in Fn.manage_pack(spec, self):
+                self._pack_dst.setdefault(src_ptr, dst_ptr)
+        self._pack_gen += 1            # cached tables were built without (or with other) destinations
+
+    def detach_packs(self):
+        from . import functional as Fn
+        for spec in self._pack_specs:
+            Fn.manage_pack(spec, None)
+        self._pack_dst, self._pack_specs = {}, []
+        self._pack_gen += 1
 
     # ------------------------------------------------------------------ API
     @torch.no_grad()

@@ -240,6 +240,23 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         self._hwres = None
         return self._hw_resolve(plan)
 
+    def weight_packs(self):
+        """the model's weight packs (functional._Spec, each with its plan) once a grad-mode forward has run: what
+        dsrg_amd.optim.AdamW.attach_packs takes"""
+        out = []
+        for plan in (self.bert._wplan, getattr(self, '_hwplan', None)):
+            spec = getattr(plan[1], '_spec_t', None) if plan is not None else None
+            if spec is not None and spec.plan is not None:
+                out.append(spec)
+        return out
+
+    def sync_packs(self):
+        """run the packs now (grad mode), so that optimizer-managed buffers are current before a capture"""
+        self.drop_grad_packs()
+        with torch.enable_grad():
+            self.bert._weights()
+            self._hw()
+
     def drop_grad_packs(self):
         """forget the differentiable weight packs (and with them the autograd nodes of the step that made them)"""
         self.bert._wgrad = None

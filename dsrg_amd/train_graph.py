@@ -63,7 +63,7 @@ class _Entry:
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, max_norm, params=None, loss_of=None, bf16_grads=False, group=None, max_graphs=16):
+    def __init__(self, model, optimizer, max_norm, params=None, loss_of=None, bf16_grads=False, group=None, max_graphs=16, manage_packs=True):
         """model: GlocalTextPathCMTPreTraining (bare, not DDP-wrapped).  optimizer: constructed with capturable=True.
         loss_of(model, batch, task) -> scalar; default = the reference's `model(batch, task, compute_loss=True).mean()`."""
         self.model, self.opt, self.max_norm = model, optimizer, float(max_norm)
@@ -81,6 +81,8 @@ class GraphedTrainStep:
         self.seed_off = torch.zeros(1, dtype=torch.int64, device=self.dev)
         K.set_dropout_offset(self.seed_off)
         self.native_opt = hasattr(optimizer, 'clip_grad_norm') and hasattr(optimizer, 'sync_hyper')
+        self.manage_packs = manage_packs and __import__('os').environ.get('DSRG_MANAGE_PACKS', '1') == '1'      # (env: A/B)
+        self._attached = False
         for g in optimizer.param_groups:
             if not self.native_opt and not g.get('capturable', False):
                 raise ValueError('GraphedTrainStep: construct a torch optimizer with capturable=True (or use dsrg_amd.optim.AdamW)')
@@ -191,6 +193,11 @@ class GraphedTrainStep:
             if not self.graphs:
                 self._drop_packs()
             loss = self._eager(batch, task)
+            if self.native_opt and self.manage_packs and not self._attached and hasattr(self.model, 'weight_packs'):
+                # from here on the optimizer's update kernel writes the bf16 weight copies: no cast pass in the captured forwards
+                self.opt.attach_packs(self.model.weight_packs())
+                self.model.sync_packs()
+                self._attached = True
             if len(self.graphs) >= self.max_graphs:
                 self.graphs.pop(next(iter(self.graphs)))
             self.graphs[key] = self._capture(batch, task)

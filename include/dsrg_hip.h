@@ -60,8 +60,10 @@ typedef struct {
   int64_t numel;
   int32_t group;        /* index into hyper */
   int32_t step_idx;     /* index into steps */
-  int32_t vec_ok;       /* p, g, m, v all 16-byte aligned */
+  int32_t vec_ok;       /* p, g, m, v all 16-byte aligned (and pack 8-byte aligned) */
   int32_t reserved_;
+  void* pack;           /* optional bf16 [numel]: receives the updated parameter rounded to bf16 - the packed / cast copy the next
+                           forward reads, so that no separate cast pass over the parameters is needed; NULL = none */
 } dsrg_opt_tensor_t;
 int dsrg_opt_chunk(void);
 /* partials[b] = sum of g^2 over block b's chunk */

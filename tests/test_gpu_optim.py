@@ -81,6 +81,24 @@ def test_adamw_large_against_oracle_and_grad_scale():
         assert np.abs(p.detach().cpu().numpy() - w).max() <= 3e-6 * max(1.0, np.abs(w).max())
 
 
+@pytest.mark.parametrize('n', [4096 * 3, 5000, 37])
+def test_adamw_writes_the_bf16_pack_copy(n):
+    """dsrg_opt_tensor_t::pack: the update kernel also stores the new parameter rounded to bf16 (what attach_packs wires up)"""
+    from dsrg_amd.optim import AdamW
+    p = torch.nn.Parameter(torch.randn(n, device='cuda'))
+    q = torch.nn.Parameter(torch.randn(64, device='cuda'))
+    opt = AdamW([p, q], lr=1e-2)
+    buf = torch.zeros(n + 8, dtype=torch.bfloat16, device='cuda')
+    opt._pack_dst = {p.data_ptr(): buf.data_ptr() + 8}            # 8-byte aligned only
+    opt._pack_gen += 1
+    for _ in range(2):
+        p.grad, q.grad = torch.randn_like(p), torch.randn_like(q)
+        opt.clip_grad_norm(1.0)
+        opt.step()
+        assert torch.equal(buf[4:4 + n], p.detach().to(torch.bfloat16))
+    assert float(buf[:4].abs().max()) == 0.0 and float(buf[4 + n:].abs().max()) == 0.0
+
+
 def test_adamw_validation_and_capture():
     from dsrg_amd.optim import AdamW
     w = torch.nn.Parameter(torch.zeros(8, device='cuda'))
