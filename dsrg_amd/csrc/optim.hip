@@ -33,16 +33,24 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(const dsrg_opt_
   const dsrg_opt_tensor_t t = tab[b.x];
   const long long base = (long long)b.y * OPT_CHUNK;
   const long long n = t.numel - base < OPT_CHUNK ? t.numel - base : OPT_CHUNK;
-  const float* g = reinterpret_cast<const float*>(t.g) + base;
+  const float* g = t.g ? reinterpret_cast<const float*>(t.g) + base : nullptr;
+  const bf16_t* g2 = t.g2 ? reinterpret_cast<const bf16_t*>(t.g2) + base : nullptr;     // the gradient (or a second share of it) in bf16
   float acc = 0.f;
   if (t.vec_ok && n == OPT_CHUNK) {
     float4 v[OPT_VEC];
 #pragma unroll
-    for (int i = 0; i < OPT_VEC; ++i) v[i] = reinterpret_cast<const float4*>(g)[threadIdx.x + i * OPT_THREADS];
+    for (int i = 0; i < OPT_VEC; ++i) {
+      const int j = threadIdx.x + i * OPT_THREADS;
+      v[i] = g ? reinterpret_cast<const float4*>(g)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g2) { const float4 h = ld4(g2 + 4 * j); v[i].x += h.x; v[i].y += h.y; v[i].z += h.z; v[i].w += h.w; }
+    }
 #pragma unroll
     for (int i = 0; i < OPT_VEC; ++i) acc += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
   } else {
-    for (long long i = threadIdx.x; i < n; i += OPT_THREADS) acc += g[i] * g[i];
+    for (long long i = threadIdx.x; i < n; i += OPT_THREADS) {
+      const float x = (g ? g[i] : 0.f) + (g2 ? bf2f(g2[i]) : 0.f);
+      acc += x * x;
+    }
   }
   const float s = block_sum(acc, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
@@ -100,7 +108,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_step_kernel(const dsrg_opt_
   }
   const float decay = wd > 0.f ? lr * wd : 0.f;
   float* p = reinterpret_cast<float*>(t.p) + base;
-  const float* g = reinterpret_cast<const float*>(t.g) + base;
+  const float* g = t.g ? reinterpret_cast<const float*>(t.g) + base : nullptr;
+  const bf16_t* g2 = t.g2 ? reinterpret_cast<const bf16_t*>(t.g2) + base : nullptr;
   float* m = t.m + base;
   float* v = t.v + base;
   bf16_t* pk = t.pack ? reinterpret_cast<bf16_t*>(t.pack) + base : nullptr;      // compute-dtype copy of the parameter (the next forward's operand)
@@ -109,8 +118,10 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_step_kernel(const dsrg_opt_
 #pragma unroll
     for (int i = 0; i < OPT_VEC; ++i) {
       const int j = threadIdx.x + i * OPT_THREADS;
-      pv[i] = reinterpret_cast<const float4*>(p)[j]; gv[i] = reinterpret_cast<const float4*>(g)[j];
+      pv[i] = reinterpret_cast<const float4*>(p)[j];
+      gv[i] = g ? reinterpret_cast<const float4*>(g)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       mv[i] = reinterpret_cast<const float4*>(m)[j]; vv[i] = reinterpret_cast<const float4*>(v)[j];
+      if (g2) { const float4 h = ld4(g2 + 4 * j); gv[i].x += h.x; gv[i].y += h.y; gv[i].z += h.z; gv[i].w += h.w; }
     }
 #pragma unroll
     for (int i = 0; i < OPT_VEC; ++i) {
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_step_kernel(const dsrg_opt_
   } else {
     for (long long i = threadIdx.x; i < n; i += OPT_THREADS) {
       float pp = p[i], mm = m[i], vv = v[i];
-      adamw_one(pp, g[i], mm, vv, coef, c, step_size, decay);
+      adamw_one(pp, (g ? g[i] : 0.f) + (g2 ? bf2f(g2[i]) : 0.f), mm, vv, coef, c, step_size, decay);
       p[i] = pp; m[i] = mm; v[i] = vv;
       if (pk) pk[i] = f2bf(pp);
     }

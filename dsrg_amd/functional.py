@@ -70,7 +70,7 @@ class _PackFn(torch.autograd.Function):
             if spec.managed is None:
                 flats = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
                 parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
-                for (dd, sd), (pidx, dets) in plan['copies'].items():
+                for (dd, sd), (pidx, dets, _) in plan['copies'].items():
                     pp = parts[dd]
                     torch._foreach_copy_([pp[j] for j in pidx], dets)
             else:
@@ -81,7 +81,7 @@ class _PackFn(torch.autograd.Function):
                 parts = {d: flats[d].split(plan['sizes'][d]) for d in flats}
                 vers = tuple(t._version for t in srcs)
                 full = plan.get('synced') != vers
-                for (dd, sd), (pidx, dets) in plan['copies'].items():
+                for (dd, sd), (pidx, dets, _) in plan['copies'].items():
                     keep = range(len(pidx)) if full else plan['unmanaged'].get((dd, sd), ())
                     if len(keep):
                         torch._foreach_copy_([parts[dd][pidx[i]] for i in keep], [dets[i] for i in keep])
@@ -113,13 +113,24 @@ class _PackFn(torch.autograd.Function):
         PACK_EPOCH[0] += 1           # the parameters are about to change: no cached pack survives this backward
         grads = [None] * len(ctx.meta)
         dst, src = [], []
+        # optimizer-managed pack with packed gradients on (optim.AdamW.packed_grads): the bf16 gradient of a packed weight is
+        # handed to the optimizer AS IT LIES (address of the source's row range) instead of being cast into an fp32 .grad
+        opt = ctx.spec.managed
+        stash = opt._gstash if (opt is not None and opt.packed_grads and ctx.spec.plan is not None) else None
+        msrc = ctx.spec.plan.get('managed_src', {}) if stash is not None else {}
         for (dtype, idxs), g in zip(ctx.spec, gouts):
             if g is None:
                 continue
             r = 0
+            lies = stash is not None and g.dtype == torch.bfloat16 and g.is_contiguous()
             for i in idxs:
                 shape, dt, dev = ctx.meta[i]
-                if ctx.needs_input_grad[1 + i]:
+                if lies and i in msrc and ctx.needs_input_grad[1 + i]:
+                    row = 1
+                    for d_ in shape[1:]:
+                        row *= int(d_)
+                    stash[msrc[i]] = (g.data_ptr() + 2 * r * row, g)
+                elif ctx.needs_input_grad[1 + i]:
                     grads[i] = torch.empty(shape, dtype=dt, device=dev)
                     dst.append(grads[i]); src.append(g[r:r + shape[0]])
                 r += shape[0]
@@ -156,14 +167,15 @@ def manage_pack(spec, optimizer):
         raise RuntimeError('manage_pack: this pack has not run yet (one forward first)')
     if optimizer is None:
         spec.managed = None
-        plan.pop('pflats', None); plan.pop('synced', None); plan.pop('unmanaged', None)
+        plan.pop('pflats', None); plan.pop('synced', None); plan.pop('unmanaged', None); plan.pop('managed_src', None)
         return []
     if 'pflats' not in plan:
         plan['pflats'] = {d: torch.empty(n, dtype=d, device=plan['dev']) for d, n in plan['total'].items()}
     plan['synced'] = None
     pairs, unmanaged, seen = [], {}, set()
     owned = {p.data_ptr() for p in optimizer._index}
-    for (dd, sd), (pidx, dets) in plan['copies'].items():
+    managed_src = {}
+    for (dd, sd), (pidx, dets, sidx) in plan['copies'].items():
         offs, o = [], 0
         for n in plan['sizes'][dd]:
             offs.append(o); o += n
@@ -173,11 +185,11 @@ def manage_pack(spec, optimizer):
         for i, (j, det) in enumerate(zip(pidx, dets)):
             sp = det.data_ptr()
             if dd == torch.bfloat16 and sd == torch.float32 and sp in owned and sp not in optimizer._pack_dst and sp not in seen:
-                pairs.append((sp, base + offs[j] * es)); seen.add(sp)
+                pairs.append((sp, base + offs[j] * es)); seen.add(sp); managed_src[sidx[i]] = sp
             else:
                 left.append(i)
         unmanaged[(dd, sd)] = left
-    plan['unmanaged'] = unmanaged
+    plan['unmanaged'], plan['managed_src'] = unmanaged, managed_src
     spec.managed = optimizer
     return pairs
 
@@ -199,8 +211,8 @@ def _pack_plan(spec, srcs):
         outs.append((dtype, shape, tuple(reversed(st)), off))
         for i in idxs:
             n = srcs[i].numel()
-            g = copies.setdefault((dtype, srcs[i].dtype), ([], []))
-            g[0].append(len(sz)); g[1].append(srcs[i].detach().view(-1))
+            g = copies.setdefault((dtype, srcs[i].dtype), ([], [], []))
+            g[0].append(len(sz)); g[1].append(srcs[i].detach().view(-1)); g[2].append(i)
             sz.append(n); off += n
         total[dtype] = off
     return {'dev': dev, 'total': total, 'sizes': sizes, 'copies': copies, 'outs': outs, 'meta': [(t.shape, t.dtype, t.device) for t in srcs],

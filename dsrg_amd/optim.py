@@ -22,7 +22,7 @@ from . import _lib
 from .kernels import _p, _stream
 
 _TENSOR = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('numel', '<i8'), ('group', '<i4'), ('step_idx', '<i4'),
-                    ('vec_ok', '<i4'), ('reserved_', '<i4'), ('pack', '<u8')])          # = dsrg_opt_tensor_t (include/dsrg_hip.h), 64 bytes
+                    ('vec_ok', '<i4'), ('reserved_', '<i4'), ('g2', '<u8'), ('pack', '<u8')])          # = dsrg_opt_tensor_t (include/dsrg_hip.h), 72 bytes
 
 
 class _Plan:
@@ -48,6 +48,8 @@ class AdamW(torch.optim.Optimizer):
         self._plans = []                # most recent first; a plan is keyed by the (parameter, gradient) addresses it was built for
         self._captured = []
         self._pack_dst, self._pack_gen, self._pack_specs = {}, 0, []      # attach_packs()
+        self.packed_grads = False       # attach_packs + True: bf16 gradients of packed weights are read as they lie (no fp32 .grad)
+        self._gstash = {}               # parameter address -> (address of its bf16 gradient, the tensor that holds it); one backward
         self._pending = None            # plan whose prepare launch (clip_grad_norm) already ran for the coming step()
         self.grad_scale = 1.0           # multiplies every gradient where it is read (1 / world size after a summing all-reduce)
 
@@ -82,12 +84,14 @@ class AdamW(torch.optim.Optimizer):
             self._hp_sent = vals
 
     def _plan(self):
-        ents = [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params'] if p.grad is not None]
+        gst = self._gstash
+        ents = [(gi, p) for gi, g in enumerate(self.param_groups) for p in g['params'] if p.grad is not None or (gst and p.data_ptr() in gst)]
         if not ents:
             return None
         self._ensure_device()
         capturing = torch.cuda.is_current_stream_capturing()
-        key = (self._pack_gen,) + tuple((p.data_ptr(), p.grad.data_ptr()) for _, p in ents)
+        key = (self._pack_gen,) + tuple((p.data_ptr(), 0 if p.grad is None else p.grad.data_ptr(), gst[p.data_ptr()][0] if p.data_ptr() in gst else 0)
+                                        for _, p in ents)
         for pl in self._plans + self._captured:
             if pl.key == key:
                 if pl.host is not None and not capturing:
@@ -97,7 +101,9 @@ class AdamW(torch.optim.Optimizer):
         tab = np.zeros(len(ents), _TENSOR)
         for i, (gi, p) in enumerate(ents):
             g = p.grad
-            if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous() or p.device != self._dev:
+            g2 = gst[p.data_ptr()][0] if p.data_ptr() in gst else 0
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != self._dev or \
+                    (g is not None and (g.dtype != torch.float32 or not g.is_contiguous())):
                 raise _lib.DsrgHipError('dsrg_amd.optim.AdamW: parameters and gradients must be contiguous fp32 tensors on %s' % self._dev)
             grp = self.param_groups[gi]
             c = (float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), bool(grp['correct_bias']))
@@ -110,9 +116,9 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError('dsrg_amd.optim.AdamW: a parameter gets its first gradient inside a stream capture; run one eager step first')
                 st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] = self._steps[self._index[p]]
-            ptrs = (p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr())
+            ptrs = (p.data_ptr(), 0 if g is None else g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr())
             pack = self._pack_dst.get(p.data_ptr(), 0)
-            tab[i] = ptrs + (p.numel(), gi, self._index[p], int(all(a % 16 == 0 for a in ptrs) and pack % 8 == 0), 0, pack)
+            tab[i] = ptrs + (p.numel(), gi, self._index[p], int(all(a % 16 == 0 for a in ptrs) and pack % 8 == 0 and g2 % 8 == 0), 0, g2, pack)
         nch = (tab['numel'] + self._chunk - 1) // self._chunk
         starts = np.cumsum(nch) - nch
         blocks = np.empty((int(nch.sum()), 2), np.int32)
@@ -122,7 +128,7 @@ class AdamW(torch.optim.Optimizer):
         pl = _Plan()
         pl.key, pl.consts, pl.n_tensors, pl.n_blocks = key, consts, len(ents), blocks.shape[0]
         pl.dev = torch.empty(raw.shape[0], dtype=torch.uint8, device=self._dev)
-        pl.table, pl.blocks = pl.dev.data_ptr(), pl.dev.data_ptr() + tab.nbytes           # 64-byte entries: the block table stays 8-byte aligned
+        pl.table, pl.blocks = pl.dev.data_ptr(), pl.dev.data_ptr() + tab.nbytes           # 72-byte entries: the block table stays 8-byte aligned
         pl.partials = torch.empty(pl.n_blocks, dtype=torch.float32, device=self._dev)
         if capturing:
             # a memcpy node that re-reads its pinned source on every replay: the source is a region of the arena that is
@@ -170,6 +176,7 @@ class AdamW(torch.optim.Optimizer):
         for spec in self._pack_specs:
             Fn.manage_pack(spec, None)
         self._pack_dst, self._pack_specs = {}, []
+        self._gstash.clear()
         self._pack_gen += 1
 
     # ------------------------------------------------------------------ API
@@ -202,4 +209,9 @@ class AdamW(torch.optim.Optimizer):
         b1, b2, eps, cb = pl.consts
         _lib.check(_lib.load().dsrg_adamw_step(pl.table, pl.blocks, pl.n_blocks, _p(self._hp), _p(self._norm), _p(self._steps),
                                                b1, b2, eps, int(cb), _stream()), 'dsrg_adamw_step')
+        self._gstash.clear()            # the handed-over gradients belong to the backward that just ended
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        self._gstash.clear()
+        return super().zero_grad(set_to_none)

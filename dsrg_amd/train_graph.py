@@ -196,6 +196,7 @@ class GraphedTrainStep:
             if self.native_opt and self.manage_packs and not self._attached and hasattr(self.model, 'weight_packs'):
                 # from here on the optimizer's update kernel writes the bf16 weight copies: no cast pass in the captured forwards
                 self.opt.attach_packs(self.model.weight_packs())
+                self.opt.packed_grads = self.world == 1        # (N ranks: the flat all-reduce buffer is built from the .grad tensors)
                 self.model.sync_packs()
                 self._attached = True
             if len(self.graphs) >= self.max_graphs:

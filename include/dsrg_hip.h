@@ -54,14 +54,17 @@ int dsrg_set_dropout_offset(const uint64_t* dev_ptr);
  * themselves are left unscaled (the coefficient is applied where the update reads them). */
 typedef struct {
   void* p;              /* parameter, fp32 [numel] */
-  const void* g;        /* gradient, fp32 [numel] */
+  const void* g;        /* gradient, fp32 [numel] (may be NULL when g2 is given) */
   float* m;             /* exp_avg */
   float* v;             /* exp_avg_sq */
   int64_t numel;
   int32_t group;        /* index into hyper */
   int32_t step_idx;     /* index into steps */
-  int32_t vec_ok;       /* p, g, m, v all 16-byte aligned (and pack 8-byte aligned) */
+  int32_t vec_ok;       /* p, g, m, v all 16-byte aligned (and g2, pack 8-byte aligned) */
   int32_t reserved_;
+  const void* g2;       /* optional bf16 [numel]: a (further) share of the gradient, added to g where it is read - the slice of a
+                           packed weight's bf16 gradient, consumed as it lies instead of being cast into an fp32 .grad first.
+                           At least one of g, g2 is non-NULL */
   void* pack;           /* optional bf16 [numel]: receives the updated parameter rounded to bf16 - the packed / cast copy the next
                            forward reads, so that no separate cast pass over the parameters is needed; NULL = none */
 } dsrg_opt_tensor_t;

@@ -63,7 +63,11 @@ def test_graphed_step_matches_eager_steps(native):
         worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(a.parameters(), b.parameters()))
         sd0 = common.synth_sd('r2r_pt')
         moved = max(float((p.detach() - sd0[k].cuda()).abs().max()) for k, p in a.state_dict().items() if p.dtype.is_floating_point)
-        assert moved > 1e-2 and worst <= 2e-4, (worst, moved)      # float atomics in the backward: run-to-run noise of ~5e-5
+        # float atomics in the backward make two runs of the SAME eager code differ by ~5e-5 .. 2e-4 here: where a gradient is
+        # near zero Adam's update flips sign (up to 2 lr per step); nine steps at lr 1e-4 bound any difference by 1.8e-3
+        assert moved > 1e-2 and worst <= 5e-4, (worst, moved)
+        far = sum(int(((p.detach() - q.detach()).abs() > 1e-4).sum()) for p, q in zip(a.parameters(), b.parameters()))
+        assert far <= 1e-5 * sum(p.numel() for p in a.parameters()), far
         # an eager forward after replays sees the replayed optimizer steps (no stale captured pack)
         a.eval(); b.eval()
         with torch.no_grad():
