@@ -53,7 +53,8 @@ class EmbedBwdArgs(C.Structure):
                                           'dE2', 'dvec', 'dlno_gamma', 'dlno_beta')] + \
                [(n, C.c_int32) for n in ('ldb', 'ldf', 'F', 'idx1_kind', 'idx1_stride', 'idx1_div', 'idx2_kind', 'idx2_stride',
                                          'idx2_div', 'lddo', 'lddb', 'M', 'H', 'dtype')] + [('eps', C.c_float), ('E1_rows', C.c_int32),
-                                                                                   ('E2_rows', C.c_int32), ('E1_padding_idx', C.c_int32), ('E1_copies', C.c_int32)]
+                                                                                   ('E2_rows', C.c_int32), ('E1_padding_idx', C.c_int32), ('E1_copies', C.c_int32),
+                                                                                   ('reserved_', C.c_int32), ('partials', C.c_void_p)]
 
 
 class GraphState(C.Structure):
@@ -128,6 +129,7 @@ SIGNATURES = {
     'dsrg_nav_logits_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_igl_blend_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_embed_ln_bwd': (C.c_int, [C.POINTER(EmbedBwdArgs), _P]),
+    'dsrg_embed_ln_bwd_workspace': (C.c_int64, [_P]),
     'dsrg_segment_wsum': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
     'dsrg_graph_reset': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_graph_observe': (C.c_int, [C.POINTER(GraphState), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

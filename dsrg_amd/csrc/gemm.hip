@@ -871,14 +871,19 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     }
   }
   // LayerNorm-fusion kinds (FUSE_A: 64x64 and 128x128x2; FUSE_RS: 64x64 and 128x64x4) and transposed operands (64x64, wgrad above)
-  bool fuse_a = false, fuse_rs = false, only64 = false;
+  bool fuse_a = false, fuse_rs = false, only64 = false, dgrad = false;
+  // DSRG_GEMM_DGRAD=1: dgrad launches (trans = 2) take the forward rules' wide tiles.  OFF by default - measured on the
+  // pre-training step (one stream, one box): 64x64 10.49 ms | wide 10.58 (bit-identical results either way).
+  static const char* dg_env = getenv("DSRG_GEMM_DGRAD");
   for (int i = 0; i < a.nprob; ++i) {
     fuse_a = fuse_a || a.p[i].a_stats;
     fuse_rs = fuse_rs || a.p[i].r_stats || a.p[i].stats_out;
-    only64 = only64 || a.p[i].trans;
+    // dgrad (dX = dY.W, W as it lies: trans = 2) takes the forward launches' wide / long-K rules below (128x128x2, 128x64x4)
+    if (a.p[i].trans == 2 && bf16 && dg_env && dg_env[0] == '1') dgrad = true;
+    else only64 = only64 || a.p[i].trans;
   }
   only64 = only64 || ((fuse_a || fuse_rs) && !bf16);        // the wide fused tiles are built for bf16
-  const bool fuse = only64 || fuse_a || fuse_rs;             // no 8-wave tile, no tuning overrides
+  const bool fuse = only64 || fuse_a || fuse_rs || dgrad;    // no 8-wave tile, no tuning overrides
   // Wide launches (every problem N >= 2304 and K <= 1024: packed QKV, FFN-in; 20 per nav-step): 128x128 with a 2-deep ring
   // (64 KiB: two workgroups per CU) from 200 tiles on - r02t A/B in DESIGN.md section 4.0.  DSRG_GEMM_WIDE /
   // DSRG_GEMM_LONGK (K >= 2048) = "BMxBNxNST:mintiles[,...]" override the candidates (tuning aid; first that reaches its
@@ -952,10 +957,13 @@ int dispatch_tile(GemmArgs& a, hipStream_t s, int fbm, int fbn, int fnst) {
   for (int i = 0; i < a.nprob; ++i) { fuse_a = fuse_a || a.p[i].a_stats; fuse_rs = fuse_rs || a.p[i].r_stats || a.p[i].stats_out; }
   if (a.p[0].trans) {      // backward GEMMs on operands as they lie (no transposed copies); bf16 checked by the entry
     const bool wg_tile = a.p[0].trans == 3 && ((bm == 128 && bn == 128 && nst == 2) || (bm == 128 && bn == 64 && nst == 3));
-    DSRG_CHECK((bm == 64 && bn == 64 && (nst == 2 || nst == 3)) || wg_tile,
-               "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3) and, trans = 3 only, 128x128x2 / 128x64x3, not %dx%dx%d", bm, bn, nst);
+    const bool dg_tile = a.p[0].trans == 2 && ((bm == 128 && bn == 128 && nst == 2) || (bm == 128 && bn == 64 && nst == 4));
+    DSRG_CHECK((bm == 64 && bn == 64 && (nst == 2 || nst == 3)) || wg_tile || dg_tile,
+               "dsrg_gemm_nt: transposed operands exist for the 64x64 tile (ring 2 or 3), trans = 3 also 128x128x2 / 128x64x3, trans = 2 also 128x128x2 / 128x64x4, not %dx%dx%d", bm, bn, nst);
     if constexpr (sizeof(T) == 2) {
       const int tr = a.p[0].trans;
+      if (tr == 2 && bm == 128 && bn == 128) return launch<T, OutT, 128, 128, 2, false, 2, 2, 2>(a, tiles, s);
+      if (tr == 2 && bm == 128 && bn == 64) return launch<T, OutT, 128, 64, 4, false, 2, 2, 2>(a, tiles, s);
       if (tr == 3 && bm == 128 && bn == 128) return launch<T, OutT, 128, 128, 2, false, 2, 2, 3>(a, tiles, s);
       if (tr == 3 && bm == 128 && bn == 64) return launch<T, OutT, 128, 64, 3, false, 2, 2, 3>(a, tiles, s);
 #define DSRG_TRANS_CASE(TR_, NST_) if (tr == TR_ && nst == NST_) return launch<T, OutT, 64, 64, NST_, false, 2, 2, TR_>(a, tiles, s)
@@ -1029,8 +1037,8 @@ int gemm_entry(const dsrg_gemm_problem_t* problems, int nproblems, int dtype, in
                "dsrg_gemm_nt: problem %d: res_act=%d needs a residual (the pre-activation) and no r_stats", i, p.res_act);
     DSRG_CHECK(p.trans >= 0 && p.trans <= 3 && p.trans == problems[0].trans, "dsrg_gemm_nt: problem %d: trans=%d must be 0..3 and the same for the whole group", i, p.trans);
     DSRG_CHECK(p.trans == 0 || (dtype == DSRG_BF16 && !p.a_stats && !p.r_stats && !p.stats_out &&
-                                (fbm <= 0 || (p.trans == 3 && fbm == 128 && (fbn == 128 || fbn == 64)))),
-               "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion; a pinned tile only with trans = 3 (128x128x2, 128x64x3)", i);
+                                (fbm <= 0 || (p.trans >= 2 && fbm == 128 && (fbn == 128 || fbn == 64)))),
+               "dsrg_gemm_nt: problem %d: transposed operands are bf16 only, without LayerNorm fusion; a pinned tile only with trans = 2 / 3 (128x128x2, 128x64x3|4)", i);
     const bool ta = (p.trans & 1) != 0, tw = (p.trans & 2) != 0;
     // a transposed operand is [K, M] / [K, N]: whole 16-byte chunks of 8 output rows / columns
     DSRG_CHECK(p.lda % al == 0 && p.lda >= (ta ? p.M : p.K) && (!ta || (p.M % 8 == 0 && p.M >= 8)),

@@ -297,8 +297,37 @@ __device__ __forceinline__ int embed_index_b(const void* p, int kind, int stride
   return (int)reinterpret_cast<const float*>(p)[o];
 }
 
+// The column-vector gradients a launch produces, in the order the kernel flushes them: where each one goes (dst + c * stride).
+constexpr int EMB_MAX_SLOTS = 32;
+struct EmbSlots { float* dst[EMB_MAX_SLOTS]; int stride[EMB_MAX_SLOTS]; int n; };
+
+// dst[c * stride] += sum_b partials[b][slot][c]: 32 columns x 32 row groups per workgroup, LDS tree, fixed order
+__global__ __launch_bounds__(1024) void embed_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int H, const EmbSlots sl) {
+  __shared__ float red[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int per = H / 32;                           // column groups per slot (H % 64 == 0)
+  const int slot = blockIdx.x / per, c = (blockIdx.x - slot * per) * 32 + cl;
+  const size_t rs = (size_t)sl.n * H;
+  const float* src = partials + (size_t)slot * H + c;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = rg;
+  for (; b + 96 < nblk; b += 128) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += src[(size_t)(b + 32 * u) * rs];
+  }
+  for (; b < nblk; b += 32) a[0] += src[(size_t)b * rs];
+  red[rg][cl] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    if (rg < o) red[rg][cl] += red[rg + o][cl];
+    __syncthreads();
+  }
+  if (rg == 0) sl.dst[slot][(size_t)c * sl.stride[slot]] += red[0][cl];
+}
+
 template <typename T, int NV, int FR, int TS>
-__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_args_t a, int rows_per_block) {
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_args_t a, int rows_per_block, int nslots) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H, F = a.F, nv = NV, HS = H + 4;
@@ -439,6 +468,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
   }
   // the four waves' register sums -> one global atomic per element per workgroup.  `on` and the loop bounds are
   // workgroup-uniform, so every thread reaches the barriers.
+  int slot = 0;
   auto flush = [&](const float4 (&acc)[NV], float* dst, int dst_stride, bool on) {
     if (!on) return;
     // LDS-only barriers: __syncthreads() also waits for the previous vector's global atomics (a ~2.5 us round trip per
@@ -447,6 +477,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const dsrg_embed_bwd_
 #pragma unroll
     ROWN(i, c) *reinterpret_cast<float4*>(slab + wave * H + c) = acc[i]; ENDV
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (a.partials) {        // this workgroup's row of the partial table; embed_bwd_reduce_kernel adds the table onto dst
+      float* prow = a.partials + ((size_t)blockIdx.x * nslots + slot) * H;
+      for (int c = threadIdx.x; c < H; c += 256) prow[c] = (slab[c] + slab[H + c]) + (slab[2 * H + c] + slab[3 * H + c]);
+      ++slot;
+      return;
+    }
     for (int c = threadIdx.x; c < H; c += 256)
       atomicAdd(dst + (size_t)c * dst_stride, (slab[c] + slab[H + c]) + (slab[2 * H + c] + slab[3 * H + c]));
   };
@@ -582,6 +618,44 @@ extern "C" int dsrg_igl_blend_bwd(const void* aug, const void* x, const float* w
   return DSRG_OK;
 }
 
+// ~256 workgroups: with the column sums in registers a longer strip per wave means fewer flushes at the end, a shorter one
+// more rows in flight (measured best for 4932 rows with the atomic flush: 89 us, against 111 us with ~512 and 98 us with ~128)
+static int embed_bwd_rows_per_block(const dsrg_embed_bwd_args_t& a) {
+  // (with the partial table instead of atomics, twice the workgroups: no difference, 10.42 vs 10.38 ms per pre-training step)
+  const int wgs = a.M >= 4096 ? 256 : a.M >= 1024 ? 128 : 64;
+  const int rpb0 = ((a.M + wgs - 1) / wgs + WPB - 1) / WPB * WPB;
+  return rpb0 < WPB ? WPB : rpb0;
+}
+// the kernel's flush order, mirrored: dWf columns, dbf, feature-LayerNorm gain / offset, rows of the small tables, the
+// constant vector, output-LayerNorm gain / offset
+static EmbSlots embed_bwd_slots(const dsrg_embed_bwd_args_t& a) {
+  EmbSlots s;
+  s.n = 0;
+  auto add = [&](float* dst, int stride) { if (s.n < EMB_MAX_SLOTS) { s.dst[s.n] = dst; s.stride[s.n] = stride; } ++s.n; };
+  const bool small1 = a.dE1 && a.E1_rows <= EMB_SMALL, small2 = a.dE2 && a.E2_rows <= EMB_SMALL;
+  if (a.feat) {
+    for (int k = 0; k < a.F; ++k) add(a.dWf + k, a.F);
+    if (a.dbf) add(a.dbf, 1);
+    if (a.lnf_gamma) { add(a.dlnf_gamma, 1); add(a.dlnf_beta, 1); }
+  }
+  if (small1) for (int r = 0; r < a.E1_rows; ++r) add(a.dE1 + (size_t)r * a.H, 1);
+  if (small2) for (int r = 0; r < a.E2_rows; ++r) add(a.dE2 + (size_t)r * a.H, 1);
+  if (a.vec) add(a.dvec, 1);
+  if (a.lno_gamma) { add(a.dlno_gamma, 1); add(a.dlno_beta, 1); }
+  for (int i = s.n; i < EMB_MAX_SLOTS; ++i) { s.dst[i] = nullptr; s.stride[i] = 0; }
+  return s;
+}
+
+extern "C" int64_t dsrg_embed_ln_bwd_workspace(const dsrg_embed_bwd_args_t* args) {
+  if (!args || args->M <= 0 || args->H <= 0) return 0;
+  dsrg_embed_bwd_args_t b = *args;
+  b.partials = reinterpret_cast<float*>(sizeof(float));      // the strip length depends on whether a workspace is given: size it for "given"
+  const int rpb = embed_bwd_rows_per_block(b);
+  const EmbSlots s = embed_bwd_slots(*args);
+  if (s.n > EMB_MAX_SLOTS) return 0;              // (cannot happen with F <= 16 and tables <= 4 rows: 16 + 3 + 4 + 4 + 3 = 30)
+  return (int64_t)((args->M + rpb - 1) / rpb) * s.n * args->H;
+}
+
 extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream) {
   DSRG_CHECK(args, "dsrg_embed_ln_bwd: null args");
   const dsrg_embed_bwd_args_t& a = *args;
@@ -605,8 +679,7 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   // wave means fewer same-address global atomics at the end, a shorter one more rows in flight
   // (inside a pre-training step the 888-row viewpoint launch took 180 us with 222 workgroups of one row per wave: ~23
   // flush vectors x 222 same-address atomics each; hence fewer, longer strips for the small launches)
-  const int wgs = a.M >= 4096 ? 256 : a.M >= 1024 ? 128 : 64;
-  const int rpb0 = ((a.M + wgs - 1) / wgs + WPB - 1) / WPB * WPB, rpb = rpb0 < WPB ? WPB : rpb0;
+  const int rpb = embed_bwd_rows_per_block(a);
   DSRG_CHECK((!a.dE1 || a.E1_rows >= 1) && (!a.dE2 || a.E2_rows >= 1), "dsrg_embed_ln_bwd: table row counts missing");
   DSRG_CHECK(a.E1_copies >= 0 && a.E1_copies <= 1024 && (a.E1_copies <= 1 || (a.dE1 && a.E1_rows > EMB_SMALL)),
              "dsrg_embed_ln_bwd: E1_copies=%d needs dE1 and a table of more than %d rows", a.E1_copies, EMB_SMALL);
@@ -615,10 +688,12 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   const size_t lds = ((size_t)WPB * a.H + (a.feat ? (size_t)a.F * (a.H + 4) : 0)) * sizeof(float);
   dim3 grid((a.M + rpb - 1) / rpb), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const EmbSlots sl = embed_bwd_slots(a);
+  DSRG_CHECK(!a.partials || (al(a.partials, 15) && a.H % 64 == 0), "dsrg_embed_ln_bwd: partials needs 16-byte alignment and H %% 64 == 0");
 #define EMB_BWD(T, NV, FR, TS)                                                                                             \
   do {                                                                                                                     \
     DSRG_SET_MAX_LDS_ONCE((&embed_ln_bwd_kernel<T, NV, FR, TS>), 96 * 1024);                                               \
-    hipLaunchKernelGGL((embed_ln_bwd_kernel<T, NV, FR, TS>), grid, block, lds, st, a, rpb);                                \
+    hipLaunchKernelGGL((embed_ln_bwd_kernel<T, NV, FR, TS>), grid, block, lds, st, a, rpb, sl.n);                          \
   } while (0)
 #define EMB_TS(T, NV, FR) do { if (ts == 0) EMB_BWD(T, NV, FR, 0); else if (ts == 1) EMB_BWD(T, NV, FR, 1); else EMB_BWD(T, NV, FR, 2); } while (0)
 #define EMB_FR(T, NV) do { if (fr == 0) EMB_TS(T, NV, 0); else if (fr == 8) EMB_TS(T, NV, 8); else EMB_TS(T, NV, 16); } while (0)
@@ -627,6 +702,8 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
 #undef EMB_FR
 #undef EMB_TS
 #undef EMB_BWD
+  if (a.partials && sl.n > 0)
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(sl.n * (a.H / 32)), dim3(1024), 0, st, a.partials, (int)grid.x, a.H, sl);
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_bwd");
   return DSRG_OK;
 }

@@ -931,6 +931,9 @@ def embed_ln_bwd(M, H, dout, base=None, feat=None, Wf=None, bf=None, lnf=None, E
         g['E1'] = torch.zeros(copies, E1.shape[0] * H, device=dev, dtype=torch.float32)
         a.dE1 = _p(g['E1'])
     a.E1_copies = copies
+    nws = int(lib.dsrg_embed_ln_bwd_workspace(C.byref(a)))
+    part = torch.empty(nws, device=dev, dtype=torch.float32) if nws > 0 else None      # per-workgroup column sums (no atomics)
+    a.partials = _p(part)
     _lib.check(lib.dsrg_embed_ln_bwd(C.byref(a), _stream()), 'dsrg_embed_ln_bwd')
     if copies > 1:
         g['E1'] = colsum(g['E1']).view(E1.shape)

@@ -509,7 +509,13 @@ typedef struct {
   int32_t E1_copies;          /* > 1: dE1 is [E1_copies][E1_rows][H] and workgroup w adds into copy w % E1_copies; the
                                * caller sums the copies.  Spreads the same-address atomics of a table with a few dozen
                                * rows (the 45 object classes take 14796 rows of a pre-training batch).  0 / 1 = one copy */
+  int32_t reserved_;
+  float* partials;            /* optional fp32 workspace of dsrg_embed_ln_bwd_workspace(args) elements (uninitialised): every
+                               * workgroup stores its column-vector sums there with plain stores and a second launch adds the
+                               * table, in a fixed order, onto the gradient buffers - instead of one float atomic per element
+                               * per workgroup onto the same few cache lines (0.4 ms of a pre-training step).  NULL = atomics */
 } dsrg_embed_bwd_args_t;
+int64_t dsrg_embed_ln_bwd_workspace(const dsrg_embed_bwd_args_t* args /*host*/);
 int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args /*host*/, void* stream);
 
 /* Segment-weighted row gather: out[r,:] = sum_{e in [seg_ptr[r], seg_ptr[r+1])} w[e] * in[idx[e],:].  Replaces the

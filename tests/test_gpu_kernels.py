@@ -94,6 +94,10 @@ def test_gemm_transposed_operands(K, M, N, K_, of32):
         out = K.gemm([(xa, xw, b, None)], 0, of32, trans=trans)[0]
         assert out.shape == base.shape and out.dtype == base.dtype
         assert torch.equal(out, base), (trans, (out.float() - base.float()).abs().max().item())
+    # round 3: the wide tiles of the dgrad (trans = 2) and wgrad (trans = 3) forms, W / A staged as 64-column blocks
+    for trans, xa, xw, tile in ((2, a, wt, (128, 128, 2)), (2, a, wt, (128, 64, 4)), (3, at, wt, (128, 128, 2)), (3, at, wt, (128, 64, 3))):
+        out = K.gemm([(xa, xw, b, None)], 0, of32, trans=trans, tile=tile)[0]
+        assert torch.equal(out, base), (trans, tile, (out.float() - base.float()).abs().max().item())
     # grouped: two problems of different shape in one launch
     a2, w2 = _r(72, K_, seed=5, dtype=dtype), _r(200, K_, seed=6, scale=0.05, dtype=dtype)
     o = K.gemm([(at, wt, b, None), (a2.T.contiguous(), w2.T.contiguous(), None, None)], 0, of32, trans=3)
