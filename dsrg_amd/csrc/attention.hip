@@ -252,13 +252,20 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
       uint8_t mkb = 1;
       if (a.kmask || a.klens) mkb = key_valid(a, b, k0 + min(tid & (KC - 1), nk - 1)) ? 1 : 0;
       float dreg[SPREL ? 32 : 1];
+      // rows of this wave that exist (a 20-node graph map: 16 for wave 0, 4 for wave 1, none for waves 2 and 3) and whether
+      // the chunk has a second 64-key half at all: both wave-uniform, so the table costs 20 row loads instead of 128
+      const int sp_rows = SPREL ? max(0, min(16, a.Nq - (bx * 64 + wave * 16))) : 0;
+      const bool sp_hi = nk > 64;
       if constexpr (SPREL) {
         if (use_sp) {          // wave w stages rows 16w .. 16w+15 of the block: two 256-byte pieces per row
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const float* dr = a.dists + ((size_t)b * a.Nq + min(bx * 64 + wave * 16 + i, a.Nq - 1)) * a.Nk + k0;
-            dreg[2 * i] = dr[min(lane, nk - 1)];
-            dreg[2 * i + 1] = dr[min(lane + 64, nk - 1)];
+            dreg[2 * i] = dreg[2 * i + 1] = 0.f;
+            if (i < sp_rows) {
+              const float* dr = a.dists + ((size_t)b * a.Nq + bx * 64 + wave * 16 + i) * a.Nk + k0;
+              dreg[2 * i] = dr[min(lane, nk - 1)];
+              if (sp_hi) dreg[2 * i + 1] = dr[min(lane + 64, nk - 1)];
+            }
           }
         }
       }
@@ -272,8 +279,10 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
         if (use_sp) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            sp[(wave * 16 + i) * SPS + lane] = dreg[2 * i] * sw + sb;
-            sp[(wave * 16 + i) * SPS + 64 + lane] = dreg[2 * i + 1] * sw + sb;
+            if (i < sp_rows) {
+              sp[(wave * 16 + i) * SPS + lane] = dreg[2 * i] * sw + sb;
+              if (sp_hi) sp[(wave * 16 + i) * SPS + 64 + lane] = dreg[2 * i + 1] * sw + sb;
+            }
           }
         }
       }
