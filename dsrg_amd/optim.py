@@ -54,7 +54,14 @@ class AdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0           # multiplies every gradient where it is read (1 / world size after a summing all-reduce)
 
     # ------------------------------------------------------------------ device state
-    PINNED_ARENA = 8 << 20          # bytes of pinned host memory for the tables of CAPTURED steps (one region per captured plan)
+    PINNED_ARENA = 8 << 20          # bytes of pinned host memory per arena chunk: the tables of CAPTURED steps (one region each)
+
+    def reserve_capture(self, nbytes=2 << 20):
+        """Call OUTSIDE a stream capture before capturing a step: makes sure the pinned arena has `nbytes` left for that step's
+        tables (pinned memory cannot be allocated inside a capture).  Older chunks stay alive with the plans that point into them."""
+        self._ensure_device()
+        if self._arena_used + nbytes > self._arena.numel():
+            self._arena, self._arena_used = torch.empty(max(self.PINNED_ARENA, nbytes), dtype=torch.uint8).pin_memory(), 0
 
     def _ensure_device(self):
         if self._dev is None:
@@ -135,7 +142,7 @@ class AdamW(torch.optim.Optimizer):
             # never handed out again (pinned memory cannot be allocated inside a capture, hence the arena)
             n = (raw.shape[0] + 63) // 64 * 64
             if self._arena_used + n > self._arena.numel():
-                raise RuntimeError('dsrg_amd.optim.AdamW: pinned table arena exhausted (%d captured plans); raise AdamW.PINNED_ARENA' % len(self._plans))
+                raise RuntimeError('dsrg_amd.optim.AdamW: pinned table arena exhausted (%d captured plans): call reserve_capture() before the capture' % len(self._captured))
             pl.host = self._arena[self._arena_used:self._arena_used + raw.shape[0]]
             self._arena_used += n
             pl.host.copy_(torch.from_numpy(raw))

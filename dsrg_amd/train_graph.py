@@ -133,6 +133,8 @@ class GraphedTrainStep:
         side = self.stream
         self.opt.zero_grad(set_to_none=True)
         self._drop_packs()
+        if self.native_opt:
+            self.opt.reserve_capture()
         e.g1, e.g2, e.flat, e.f32 = torch.cuda.CUDAGraph(), None, None, None
         with torch.cuda.graph(e.g1, pool=self.pool, stream=side), K.zero_pool_capture_scope():
             self.seed_off.add_(1)
