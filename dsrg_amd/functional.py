@@ -229,8 +229,23 @@ class WeightPacker:
         def __init__(self, k):
             self.k = k
 
+    class _View:
+        __slots__ = ('src', 'shape')
+
+        def __init__(self, src, shape):
+            self.src, self.shape = src, shape
+
     def __init__(self):
         self.srcs, self.spec = [], []
+
+    @staticmethod
+    def view(t, shape):
+        """placeholder for t.reshape(shape), t a parameter or a cast()/cat() placeholder.  The view is taken at resolve()
+        time, in the caller's grad mode: a view of a parameter that was taken while the weight dict was being built would
+        carry that moment's grad mode (none: the weight silently stops training) and, with autograd on, would keep the
+        parameter's AccumulateGrad node - pinned to the stream of that first forward - alive for as long as the plan lives
+        (which breaks a later HIP-graph capture of the step on another stream)."""
+        return WeightPacker._View(t, tuple(shape))
 
     def cat(self, ts, dtype):
         idxs = []
@@ -245,19 +260,21 @@ class WeightPacker:
         return self.cat([t], dtype)
 
     def resolve(self, W):
-        if not self.spec:
-            return W
-        spec = getattr(self, '_spec_t', None)
-        if spec is None or len(spec) != len(self.spec):
-            spec = self._spec_t = _Spec(self.spec)
-        if _needs_grad(self.srcs):
-            outs = _PackFn.apply(spec, *self.srcs)
-        else:
-            with torch.no_grad():
-                outs = _PackFn.forward(_NoCtx(), spec, *self.srcs)
+        outs = ()
+        if self.spec:
+            spec = getattr(self, '_spec_t', None)
+            if spec is None or len(spec) != len(self.spec):
+                spec = self._spec_t = _Spec(self.spec)
+            if _needs_grad(self.srcs):
+                outs = _PackFn.apply(spec, *self.srcs)
+            else:
+                with torch.no_grad():
+                    outs = _PackFn.forward(_NoCtx(), spec, *self.srcs)
         for k, v in W.items():
             if isinstance(v, WeightPacker._Lazy):
                 W[k] = outs[v.k]
+            elif isinstance(v, WeightPacker._View):
+                W[k] = (outs[v.src.k] if isinstance(v.src, WeightPacker._Lazy) else v.src).reshape(v.shape)
         return W
 
 

@@ -137,14 +137,23 @@ class GraphedTrainStep:
             self.opt.reserve_capture()
         e.g1, e.g2, e.flat, e.f32 = torch.cuda.CUDAGraph(), None, None, None
         with torch.cuda.graph(e.g1, pool=self.pool, stream=side), K.zero_pool_capture_scope():
-            self.seed_off.add_(1)
-            e.loss = self._fwd_bwd(e.static, task)
-            e.grads = [p.grad for p in self.params if p.grad is not None]
-            if self.world > 1:
-                flat = torch.cat([g.reshape(-1) for g in e.grads])
-                e.flat = flat.to(torch.bfloat16) if self.bf16_grads else flat
-            else:
-                self._update()
+            try:
+                self.seed_off.add_(1)
+                e.loss = self._fwd_bwd(e.static, task)
+                e.grads = [p.grad for p in self.params if p.grad is not None]
+                if self.world > 1:
+                    flat = torch.cat([g.reshape(-1) for g in e.grads])
+                    e.flat = flat.to(torch.bfloat16) if self.bf16_grads else flat
+                else:
+                    self._update()
+            except BaseException:
+                # ending a capture that an error has invalidated can take the process down inside the HIP runtime before the
+                # exception surfaces: say what happened first
+                import sys, traceback
+                print('GraphedTrainStep: error inside the stream capture of task %r:' % (task,), file=sys.stderr)
+                traceback.print_exc()
+                sys.stderr.flush()
+                raise
         if self.world > 1:
             owners = [p for p in self.params if p.grad is not None]
             f32 = e.flat if e.flat.dtype == torch.float32 else torch.empty(e.flat.numel(), dtype=torch.float32, device=self.dev)
@@ -194,7 +203,16 @@ class GraphedTrainStep:
         if e is None:
             if not self.graphs:
                 self._drop_packs()
-            loss = self._eager(batch, task)
+            import warnings
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter('always')
+                loss = self._eager(batch, task)
+            for w in seen:
+                if "AccumulateGrad node's stream does not match" in str(w.message):
+                    # capturing now would pull that other stream into the capture and die in hipStreamEndCapture
+                    raise RuntimeError('GraphedTrainStep: an autograd graph that was built on another stream is still alive (a loss or '
+                                       'output tensor of an earlier forward of this model): delete it before the first step()')
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
             if self.native_opt and self.manage_packs and not self._attached and hasattr(self.model, 'weight_packs'):
                 # from here on the optimizer's update kernel writes the bf16 weight copies: no cast pass in the captured forwards
                 self.opt.attach_packs(self.model.weight_packs())

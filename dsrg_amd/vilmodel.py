@@ -303,11 +303,11 @@ class GlocalTextPathNavCMT(nn.Module):
             lin('igl.q', le.instr_actobj_encoder.query)
             packed('igl.kv', [le.instr_actobj_encoder.key, le.instr_actobj_encoder.value])
             for k, m in (('igl.aug', le.instr_aug_linear), ('igl.ori', le.instr_ori_linear)):
-                W[k + '.w'], W[k + '.b'] = f(m.weight.reshape(-1)), f(m.bias)
+                W[k + '.w'], W[k + '.b'] = pk.view(f(m.weight), (-1,)), f(m.bias)
 
         lin('img.lin', ie.img_linear); ln('img.ln', ie.img_layer_norm)
         W['loc.w'], W['loc.b'] = f(ie.loc_linear.weight), f(ie.loc_linear.bias); ln('loc.ln', ie.loc_layer_norm)
-        W['gaa.w'], W['gaa.b'] = f(ie.adaptive_pano_attn.weight.reshape(-1)), f(ie.adaptive_pano_attn.bias)
+        W['gaa.w'], W['gaa.b'] = pk.view(f(ie.adaptive_pano_attn.weight), (-1,)), f(ie.adaptive_pano_attn.bias)
         if self.REVERIE:
             lin('objv1.lin', ie.obj_reverie_linear); ln('objv1.ln', ie.obj_reverie_layer_norm)
         W['obj.bbox.w'], W['obj.bbox.b'] = f(ie.obj_bbox_linear.weight), f(ie.obj_bbox_linear.bias)
@@ -332,7 +332,7 @@ class GlocalTextPathNavCMT(nn.Module):
         W['vp.pos.w'], W['vp.pos.b'] = f(lo.vp_pos_embeddings[0].weight), f(lo.vp_pos_embeddings[0].bias)
         ln('vp.pos.ln', lo.vp_pos_embeddings[1])
         if ge.sprel_linear is not None:
-            W['sprel.w'], W['sprel.b'] = f(ge.sprel_linear.weight.reshape(-1)), f(ge.sprel_linear.bias)
+            W['sprel.w'], W['sprel.b'] = pk.view(f(ge.sprel_linear.weight), (-1,)), f(ge.sprel_linear.bias)
         kv = []
         for br, enc in (('g', ge.encoder), ('l', lo.encoder)):
             for i, L in enumerate(enc.x_layers):
@@ -375,7 +375,7 @@ class GlocalTextPathNavCMT(nn.Module):
     def _cls_head_weights(self, W, key, hd, lin, ln, f):
         lin(key + '.l1', hd.net[0]); ln(key + '.ln', hd.net[2])
         if hd.net[3].out_features == 1:
-            W[key + '.w2'], W[key + '.b2'] = f(hd.net[3].weight.reshape(-1)), f(hd.net[3].bias)
+            W[key + '.w2'], W[key + '.b2'] = Fn.WeightPacker.view(f(hd.net[3].weight), (-1,)), f(hd.net[3].bias)
         else:
             lin(key + '.l2', hd.net[3])
 

@@ -88,3 +88,23 @@ def test_agent_snapshot_round_trip(tmp_path, prefix, monkeypatch):
         assert torch.equal(x, y), k
     for (k, x), (_, y) in zip(ca.state_dict().items(), cb.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+def test_weight_plan_views_follow_the_grad_mode_of_each_resolve():
+    """A weight plan is built once and resolved every step.  Reshaped weights (the [1,H] score layers) must be re-viewed at
+    every resolve: a view taken while the plan was built would freeze the grad mode of that first call (no gradient when the
+    first forward ran under no_grad) and would keep the parameter's AccumulateGrad node alive for the plan's lifetime."""
+    from dsrg_amd import functional as Fn
+    w32 = torch.nn.Parameter(torch.randn(1, 8))
+    w16 = torch.nn.Parameter(torch.randn(1, 8))
+    pk = Fn.WeightPacker()
+    W0 = {'a': pk.view(w32, (-1,)), 'b': pk.view(pk.cast(w16, torch.bfloat16), (-1,))}
+    with torch.no_grad():
+        W = pk.resolve(dict(W0))
+    assert W['a'].grad_fn is None and W['b'].grad_fn is None and W['a'].shape == (8,) and W['b'].dtype == torch.bfloat16
+    W = pk.resolve(dict(W0))
+    assert W['a'].grad_fn is not None and W['b'].grad_fn is not None
+    (W['a'].sum() + W['b'].float().sum()).backward()
+    assert torch.equal(w32.grad, torch.ones(1, 8)) and torch.equal(w16.grad, torch.ones(1, 8))
+    # nothing the plan holds (placeholders, packer sources) carries an autograd node of a parameter
+    assert all(not isinstance(v, torch.Tensor) or v.grad_fn is None for v in list(W0.values()) + pk.srcs)

@@ -112,3 +112,44 @@ def test_prepare_fills_what_the_forward_reads():
         assert all(b['_prep'][k] is before[k] for k in keys)
         plain = m({k: v for k, v in b.items() if k != '_prep'}, t, compute_loss=True)
         assert torch.equal(loss, plain)
+
+
+def test_prepare_reverie_tasks_and_graphed_og_step():
+    """REVERIE twin (views + objv1 object tokens per step; mlm / mrc with the object-region branch / sap / og): prepare() from
+    the batch alone must build exactly what the forward would, and an og step replays as a graph."""
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.pretrain_reverie import GlocalTextPathCMTPreTraining
+    from dsrg_amd.train_graph import GraphedTrainStep
+    from dsrg_amd.optim import AdamW
+    from dsrg_amd import kernels as K
+    from tests.test_oracle_pt_golden import PT_CFG_REVERIE
+    gold = common.load_gold('reverie_pt')
+    B, L, O, seed = [int(x) for x in gold['meta']]
+    m = GlocalTextPathCMTPreTraining(DSRGConfig(**PT_CFG_REVERIE), compute_dtype=torch.bfloat16)
+    m.load_state_dict(common.synth_sd('reverie_pt'))
+    m = m.cuda().train()
+    bs = {t: common.to_t(synth.pretrain_batch(B, L, O, seed, t, reverie=True), 'cuda') for t in ('mlm', 'mrc', 'sap', 'og')}
+    with torch.no_grad():              # the weight plan is built here, without autograd: the later steps must still train
+        m({k: v for k, v in bs['sap'].items()}, 'sap', compute_loss=True)
+    for t, b in bs.items():
+        m.prepare(b, t)
+        keys = set(b['_prep'])
+        loss = m(b, t, compute_loss=True)
+        assert set(b['_prep']) == keys, (t, set(b['_prep']) ^ keys)
+        plain = m({k: v for k, v in b.items() if k != '_prep'}, t, compute_loss=True)
+        assert torch.equal(loss, plain), t
+    # the [1,H] score layers reach the kernels as reshaped views: they get gradients whatever mode the plan was built in
+    m({k: v for k, v in bs['sap'].items() if k != '_prep'}, 'sap', compute_loss=True).mean().backward()
+    for w in (m.bert.img_embeddings.adaptive_pano_attn.weight, m.global_sap_head.net[3].weight, m.local_sap_head.net[3].weight):
+        assert w.grad is not None and float(w.grad.abs().sum()) > 0
+    m.zero_grad(set_to_none=True)
+    # everything above ran on the default stream; once its autograd graphs are gone the same model can be captured
+    del loss, plain
+    m.drop_grad_packs()
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-5)
+    gs = GraphedTrainStep(m, opt, 5.0)
+    try:
+        losses = [float(gs.step(bs['og'], 'og')) for _ in range(3)]
+        assert all(l == l and abs(l) < 1e3 for l in losses) and len(gs.graphs) == 1
+    finally:
+        K.set_dropout_offset(None)
