@@ -5,6 +5,7 @@
 //   grid = (ceil(Nq/16), NH, B), 256 threads = 4 waves, each wave owns 4 query rows.
 //   scores : lane <-> key   (K tile rows padded to 68 floats: conflict-free ds_read_b128)
 //   P·V    : lane <-> d     (V tile row-major: conflict-free ds_read_b32, P broadcast from LDS)
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -420,6 +421,189 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
   }
   ATTN_STAMP(2);
   if (!active) return;
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (qrow < a.Nq) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      st4(Op + (size_t)qrow * a.o_rs + dt * 16 + 4 * g, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
+    if (a.lse && g == 0) a.lse[((size_t)b * a.NH + h) * a.Nq + qrow] = m_run + logf(l_run);
+  }
+  ATTN_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Short-key variant of the bf16 MFMA attention (every problem of the launch has Nk <= 128, no dropout): the nav-step's
+// launches are 768 workgroups that each live for one dependent chain  global load -> LDS write -> barrier -> LDS read ->
+// S -> softmax -> P.V -> store  (in-kernel stamps, profiles/r03s_attn_stamps_before.txt: 5.8 k cycles of staging + 3.9 k of
+// compute per workgroup for ~30 MFMAs).  Here the chain is shorter:
+//   * the K fragments of S^T = K.Q^T are the MFMA's A operand exactly as K lies in memory (lane (c, g) holds 8 consecutive
+//     head-dim values of key row c), so they are loaded from global memory straight into registers - no LDS round trip and no
+//     barrier in front of the scores;
+//   * V is staged ROW-major with plain 16-byte LDS writes (160-byte rows: the 8 rows a 32-lane half of a transposing read
+//     touches fall into 8 different 32-byte bank groups) and its transposed fragments V^T[d][8 keys] come out through the
+//     gfx950 transposing read ds_read_b64_tr_b16 - instead of 32 two-byte LDS writes per thread for the transposed image;
+//   * key validity is one ballot per 64 keys (lane <-> key: a mask byte or a length compare), kept in scalar registers: no
+//     mask-term table in LDS, so the only barrier sits between the softmax and P.V, where V's loads have long landed;
+//   * the V loads are issued first, then Q / K / pair distances: the LDS writes wait for the oldest loads only.
+// NTL = number of 16-key tiles (2, 4, 6, 8) of the LONGEST problem of the launch, a template parameter so that a launch
+// of 20-key problems carries 16 K-fragment registers, not 64.  Same arithmetic, in the same order, as attention_mfma_kernel.
+constexpr int VDS = 160;
+template <int NTL, bool SPREL>
+__global__ __launch_bounds__(256, NTL <= 6 ? 3 : 2) void attention_mfma_direct_kernel(const AttnGroup grp) {
+  ATTN_STAMP(0);
+  ATTN_PICK_PROBLEM(grp)
+  constexpr int NP = NTL / 2;                                   // 32-row passes of the V stage
+  __shared__ __attribute__((aligned(16))) char Vs[NTL * 16 * VDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (bx * 4 + wave) * 16;
+  const bool active = q0 < a.Nq;                               // wave-uniform
+  const int nk = a.Nk;
+  const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
+  const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + b * a.v_bs + h * DH;
+  bf16_t* Op = reinterpret_cast<bf16_t*>(a.O) + b * a.o_bs + h * DH;
+  const int qrow = q0 + c16;
+  const int qr = min(qrow, a.Nq - 1);                           // rows past Nq repeat the last one (never stored)
+
+  // ---- all global loads in the order they are consumed (completion is counted in issue order): the validity bytes /
+  // lengths, V rows (whole workgroup), then this wave's Q / K fragments and pair distances
+  bool kv0 = true, kv1 = true;
+  if (a.kmask || a.klens) {
+    kv0 = key_valid(a, b, min(lane, nk - 1));
+    if (NTL > 4) kv1 = key_valid(a, b, min(lane + 64, nk - 1));
+  }
+  uint4 vreg[NP];
+  {
+    const int r = tid >> 3, c = tid & 7;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)min(r + 32 * p, nk - 1) * a.v_rs + c * 8);
+  }
+  uint4 qf[2], kf[NTL][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const uint4*>(Qp + (size_t)qr * a.q_rs + kk * 32 + g * 8);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      kf[t][kk] = *reinterpret_cast<const uint4*>(Kp + (size_t)min(t * 16 + c16, nk - 1) * a.k_rs + kk * 32 + g * 8);
+  const bool use_sp = SPREL && a.dists != nullptr;              // workgroup-uniform (a grouped launch may mix problems)
+  float dreg[SPREL ? NTL : 1][4];
+  float sw = 0.f, sb = 0.f;
+  if constexpr (SPREL) {
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) dreg[t][0] = dreg[t][1] = dreg[t][2] = dreg[t][3] = 0.f;
+    if (use_sp) {
+      sw = a.sprel_w[0]; sb = a.sprel_b[0];
+      const float* dr = a.dists + ((size_t)b * a.Nq + qr) * nk;
+      const bool al = (nk & 3) == 0;                             // rows of pair distances are 16-byte aligned
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int k4 = t * 16 + 4 * g;
+        if (al && k4 + 3 < nk) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dr + k4);
+          dreg[t][0] = d4.x; dreg[t][1] = d4.y; dreg[t][2] = d4.z; dreg[t][3] = d4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k4 + r < nk) dreg[t][r] = dr[k4 + r];
+        }
+      }
+    }
+  }
+  // ---- key validity: lane <-> key (and key + 64), one ballot each
+  unsigned long long vb[2] = {~0ull, ~0ull};
+  if (a.kmask || a.klens) {
+    vb[0] = __ballot(kv0);
+    if (NTL > 4) vb[1] = __ballot(kv1);
+  }
+  const int mode = a.mask_mode;
+  const float m_bad = mode == DSRG_MASK_NEG10000 ? -10000.0f : (mode == DSRG_MASK_NEGINF ? -INFINITY : 0.f);
+  const float m_ok = mode == DSRG_MASK_PLUS1 ? 1.0f : 0.f;
+
+  // ---- V rows into LDS (rows >= nk are zero: their probabilities are, too, and 0 x anything finite adds nothing)
+  {
+    const int r = tid >> 3, c = tid & 7;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int row = r + 32 * p;
+      *reinterpret_cast<uint4*>(Vs + row * VDS + c * 16) = row < nk ? vreg[p] : make_uint4(0, 0, 0, 0);
+    }
+  }
+  ATTN_STAMP(1);
+  f32x4 s[NTL];
+  float m_run = -INFINITY, l_run = 0.f;
+  if (active) {
+    // ---- S^T tiles
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[t][kk]), __builtin_bit_cast(bf16x8, qf[kk]), s[t], 0, 0, 0);
+    }
+    // ---- scale + mask + sprel, max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const unsigned bits = (unsigned)(vb[t >> 2] >> ((t & 3) * 16 + 4 * g));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * g + r;
+        float mm = ((bits >> r) & 1u) ? m_ok : m_bad;
+        if (key >= nk) mm = -INFINITY;
+        if constexpr (SPREL) {
+          if (use_sp) mm += dreg[t][r] * sw + sb;
+        }
+        const float v = s[t][r] * a.scale + mm;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    m_run = mx;
+    const float m_safe = (mx == -INFINITY) ? 0.f : mx;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[t][r] - m_safe);
+        s[t][r] = p;
+        psum += p;
+      }
+    l_run = psum;
+  }
+  __syncthreads();                                              // V staged (every wave, active or not, wrote its rows)
+  if (!active) return;
+  // ---- O^T = V^T . P^T, P straight from the score accumulators (k-slot 8g+e <-> key 32j + 4g + e, e < 4; 32j + 16 + 4g + e - 4)
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef short v4s __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < NTL / 2; ++j) {
+    bf16x8 pf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      // the 16 lanes of group g supply rows 32j + 4g .. +3 (lane: row c16 >> 2, columns 4 (c16 & 3) .. +3 of the d-tile) and
+      // each receives ITS column d = 16 dt + c16 of those four rows; the second read is the same 16 keys further on
+      const char* vp = Vs + (32 * j + 4 * g + (c16 >> 2)) * VDS + (dt * 16 + 4 * (c16 & 3)) * 2;
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(vp));
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(vp + 16 * VDS));
+      const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      const uint4 vf = make_uint4(l2.x, l2.y, h2.x, h2.y);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+    }
+  }
+  ATTN_STAMP(2);
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
   if (qrow < a.Nq) {
@@ -1070,7 +1254,28 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
   hipStream_t st = (hipStream_t)stream;
   bool any_dists = false;
   for (int i = 0; i < grp.n; ++i) any_dists = any_dists || grp.a[i].dists != nullptr;
-  if (mfma_ok) {
+  int max_nk = 0;
+  for (int i = 0; i < grp.n; ++i) max_nk = grp.a[i].Nk > max_nk ? grp.a[i].Nk : max_nk;
+  // DSRG_ATTN_DIRECT (A/B aid): 0 = never, 2 = whenever it applies, default = only when the K rows lie in a packed q|k|v or
+  // k|v buffer: three waves of a workgroup each fetch every K row, which is cheap out of L2 (the projection just written)
+  // and a loss for the text K/V panel, whose 15.7 MB per launch come cold from HBM (r03s stamps: cross-attention workgroups
+  // 11.3-11.9 k cycles direct vs 10.5-10.8 k staged; self-attention 5.5-7.5 k vs 7.3-8.8 k)
+  static const int direct_mode = []() { const char* e = getenv("DSRG_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
+  bool k_near = true;
+  for (int i = 0; i < grp.n; ++i) k_near = k_near && grp.a[i].k_rs <= 4 * NH * 64;
+  if (mfma_ok && !drop && max_nk <= KC && (direct_mode == 2 || (direct_mode == 1 && k_near))) {
+    const int ntl = ((max_nk + 31) / 32) * 2;
+#define DSRG_ATTN_DIRECT_LAUNCH(NTL_)                                                                         \
+    do {                                                                                                      \
+      if (any_dists) hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, true>), grid, block, 0, st, grp);  \
+      else hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, false>), grid, block, 0, st, grp);           \
+    } while (0)
+    if (ntl == 2) DSRG_ATTN_DIRECT_LAUNCH(2);
+    else if (ntl == 4) DSRG_ATTN_DIRECT_LAUNCH(4);
+    else if (ntl == 6) DSRG_ATTN_DIRECT_LAUNCH(6);
+    else DSRG_ATTN_DIRECT_LAUNCH(8);
+#undef DSRG_ATTN_DIRECT_LAUNCH
+  } else if (mfma_ok) {
     if (any_dists) {
       if (drop) hipLaunchKernelGGL((attention_mfma_kernel<true, true>), grid, block, 0, st, grp);
       else hipLaunchKernelGGL((attention_mfma_kernel<false, true>), grid, block, 0, st, grp);

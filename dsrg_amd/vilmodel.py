@@ -187,6 +187,8 @@ class GlocalTextPathNavCMT(nn.Module):
         # two-stream schedule: branches captured launch by launch in turn instead of one whole branch after the other
         # (measured: no difference in the replayed graph, 1.1976 vs 1.1995 ms; off)
         self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
+        # panorama call: view chain and object-token chain captured launch by launch in turn (A/B in DESIGN.md)
+        self.interleave_pano = os.environ.get('DSRG_INTERLEAVE_PANO', '1') == '1'
         self._fold = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
@@ -447,6 +449,10 @@ class GlocalTextPathNavCMT(nn.Module):
     # ---------------------------------------------------------------- panorama
     def _objv2_tokens(self, W, fts, lens, nav_types):
         """ASV: object tokens -> self-encoder -> per-view mean [B*V,128] rows (vilmodel.py:697-714)."""
+        return self._drain(self._objv2_tokens_gen(W, fts, lens, nav_types))
+
+    def _objv2_tokens_gen(self, W, fts, lens, nav_types):
+        """(generator: yields between launches, returns the result - see _run_interleaved)"""
         cfg, cd = self.config, self.compute_dtype
         B, V, O, _ = fts.shape
         d = cfg.obj_v2_size
@@ -459,19 +465,25 @@ class GlocalTextPathNavCMT(nn.Module):
             valid = K.KeyLens(lens.reshape(B, V).contiguous(), O)      # the attention kernel forms the mask from the lengths
         else:
             valid = (_arange(O, fts.device)[None, None] < lens[..., None]).reshape(B, V * O).contiguous()
+        yield
         if self._fuse_ok(d):
-            e = self._bert_layers_fused(W, ['objenc.%d' % i for i in range(2)], e, d // 64, valid, MASK_PLUS1)
+            e = yield from self._bert_layers_fused_gen(W, ['objenc.%d' % i for i in range(2)], e, d // 64, valid, MASK_PLUS1)
         else:
             for i in range(2):
                 e = self._bert_layer(W, 'objenc.%d' % i, e, d // 64, valid, MASK_PLUS1)   # bool mask ADDED (+1/+0)
+                yield
         return e.reshape(B * V * O, d), O
 
     def _pano_encoder(self, W, x, masks):
         """2 pre-norm layers over packed-in_proj MHA with -inf key padding (transformer.py:170-182)."""
+        return self._drain(self._pano_encoder_gen(W, x, masks))
+
+    def _pano_encoder_gen(self, W, x, masks):
+        """(generator: yields between launches, returns the result - see _run_interleaved)"""
         cfg = self.config
         H, nh, p = cfg.hidden_size, cfg.num_attention_heads, cfg.hidden_dropout_prob
         if self._fuse_ok(H):
-            return self._pano_encoder_fused(W, x, masks)
+            return (yield from self._pano_encoder_fused_gen(W, x, masks))
         for i in range(cfg.num_pano_layers):
             k = 'pano.%d' % i
             y = Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5)
@@ -487,6 +499,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 x = self._drop(Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b']), p, x)
             else:
                 x = Fn.linear(hdn, W[k + '.ff2.w'], W[k + '.ff2.b'], residual=x)
+            yield
         return x
 
     def _pano_tokens(self, W, base, loc_fts, nav_types, seg=None):
@@ -514,6 +527,53 @@ class GlocalTextPathNavCMT(nn.Module):
         return cat
 
     # ---------------------------------------------------------------- independent sub-graphs on a second HIP stream
+    @staticmethod
+    def _drain(gen):
+        """run a launch generator to its end -> its return value"""
+        while True:
+            try:
+                next(gen)
+            except StopIteration as e:
+                return e.value
+
+    def _side(self, cur):
+        if self._side_stream is None:
+            self._side_stream = {}
+        side = self._side_stream.get(cur.cuda_stream)          # one side stream per calling stream
+        if side is None:
+            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
+        return side
+
+    def _run_interleaved(self, side_gen, main_gen):
+        """Two independent launch chains (generators that yield between launches): `side_gen` on the side stream, `main_gen` on
+        the current one, advanced in turn so that their nodes enter a captured HIP graph interleaved - hipGraphLaunch submits
+        kernel nodes in creation order, and a chain captured as a whole before the other one delays the other's first launch
+        by its own submission time.  No-grad mode only.  -> (side result, main result); the current stream has waited for the
+        side stream on return."""
+        cur = torch.cuda.current_stream()
+        side = self._side(cur)
+        side.wait_stream(cur)
+        gens = [(side, side_gen), (cur, main_gen)]
+        res, live = [None, None], [0, 1]
+        self._fork_depth += 1
+        try:
+            while live:
+                for i in list(live):
+                    with torch.cuda.stream(gens[i][0]):
+                        try:
+                            next(gens[i][1])
+                        except StopIteration as e:
+                            res[i] = e.value
+                            live.remove(i)
+        finally:
+            self._fork_depth -= 1
+        cur.wait_stream(side)
+        r = res[0]
+        for t in (r if isinstance(r, (tuple, list)) else (r,)):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+        return res[0], res[1]
+
     def _fork(self, fn):
         """Run fn() on the model's side stream (no-grad mode only) and return join() -> its result.  The object-token
         encoder and the view encoder of a panorama, or the SAP heads and the RMF poolers of a navigation step, are
@@ -523,11 +583,7 @@ class GlocalTextPathNavCMT(nn.Module):
             r = fn()                                                                       # forks crash hipStreamEndCapture
             return lambda: r
         cur = torch.cuda.current_stream()
-        if self._side_stream is None:
-            self._side_stream = {}
-        side = self._side_stream.get(cur.cuda_stream)          # one side stream per calling stream (forks may nest)
-        if side is None:
-            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
+        side = self._side(cur)
         side.wait_stream(cur)
         self._fork_depth += 1
         try:
@@ -563,16 +619,35 @@ class GlocalTextPathNavCMT(nn.Module):
         W, cfg, cd = self._weights(), self.config, self.compute_dtype
         B, V, _ = view_img_fts.shape
         H, d = cfg.hidden_size, cfg.obj_v2_size
-        objs = self._fork(lambda: self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types))
-        img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
-        x = self._pano_tokens(W, img, loc_fts, nav_types)
-        km, pano_masks = self._len_masks(view_lens, V, want_masks)
-        x = self._pano_encoder(W, x, km)
-        obj_rows, O = objs()
         g, b = W['pano.norm.g'], W['pano.norm.b']
-        cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
-                            lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
-                            B, V, H, d, x.device)
+        km, pano_masks = self._len_masks(view_lens, V, want_masks)
+        if self.interleave_pano and not torch.is_grad_enabled() and self.overlap_streams and self._fork_depth == 0:
+            # inference: the view chain (img_linear -> tokens -> panorama encoder -> norm) on the current stream and the object-token
+            # chain (ASV encoder -> per-view mean) on the side stream, captured launch by launch in turn; both write their half
+            # of the [pano | obj] rows that vis_obj_linear reads (vilmodel.py:731)
+            cat = torch.empty(B, V, H + d, device=view_img_fts.device, dtype=cd)
+
+            def obj_chain():
+                obj_rows, O = yield from self._objv2_tokens_gen(W, obj_img_fts, obj_lens, nav_types)
+                K.group_mean(obj_rows, O, out=cat[..., H:])
+
+            def view_chain():
+                img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
+                yield
+                x = self._pano_tokens(W, img, loc_fts, nav_types)
+                yield
+                x = yield from self._pano_encoder_gen(W, x, km)
+                Fn.layernorm(x, g, b, 1e-12, out=cat[..., :H])
+            self._run_interleaved(obj_chain(), view_chain())
+        else:
+            objs = self._fork(lambda: self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types))
+            img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
+            x = self._pano_tokens(W, img, loc_fts, nav_types)
+            x = self._pano_encoder(W, x, km)
+            obj_rows, O = objs()
+            cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
+                                lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
+                                B, V, H, d, x.device)
         pano = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out=pano_out)
         fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'], scatter=gmap_scatter)
         return pano, pano_masks, fused
@@ -660,6 +735,9 @@ class GlocalTextPathNavCMT(nn.Module):
         return K.gemm([(h, W[lin + '.w'], W[lin + '.b'], res)], ACT_NONE, out_f32, fuse=[d])[0], st
 
     def _bert_layers_fused(self, W, keys, x, nh, kmask, mode):
+        return self._drain(self._bert_layers_fused_gen(W, keys, x, nh, kmask, mode))
+
+    def _bert_layers_fused_gen(self, W, keys, x, nh, kmask, mode):
         """Post-LN BERT layers (vilmodel.py:219-232; the ASV object self-encoder) without their LayerNorm launches: every
         sub-block leaves its un-normalised sum and the partial statistics, the projections that read it carry the correction
         in their epilogue; one LayerNorm launch at the end materialises the output."""
@@ -668,15 +746,20 @@ class GlocalTextPathNavCMT(nn.Module):
         t, st, lnk = x.contiguous(), None, None
         for key in keys:
             qkv = self._fz_proj(W, t, st, lnk, key + '.qkv', eps)
+            yield
             a = K.attention_grouped([(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, None)], nh, mode)[0]
+            yield
             t, st = self._fz_dense_res(W, a, key + '.ao', t, st, lnk, eps)
+            yield
             lnk = key + '.aln'
             h = self._fz_proj(W, t, st, lnk, key + '.ff1', eps, ACT_GELU)
+            yield
             t, st = self._fz_dense_res(W, h, key + '.ff2', t, st, lnk, eps)
+            yield
             lnk = key + '.fln'
         return K.layernorm_grouped([(t, W[lnk + '.g'], W[lnk + '.b'], None)], eps, self.compute_dtype)[0]
 
-    def _pano_encoder_fused(self, W, x, masks):
+    def _pano_encoder_fused_gen(self, W, x, masks):
         """The pre-norm panorama encoder (transformer.py:170-182) with norm1 / norm2 folded into the projections that read
         them: the residual stream x stays un-normalised anyway; out_proj / linear2 (+ residual) also write its partial
         statistics.  Only the first norm1 (its input comes from the embedding kernel) is a launch."""
@@ -689,10 +772,15 @@ class GlocalTextPathNavCMT(nn.Module):
                 qkv = K.gemm([(Fn.layernorm(x, W[k + '.n1.g'], W[k + '.n1.b'], 1e-5), W[k + '.qkv.w'], W[k + '.qkv.b'], None)])[0]
             else:
                 qkv = self._fz_proj(W, x, st, k + '.n1', k + '.qkv', 1e-5)
+            yield
             a = Fn.attention_packed(qkv, nh, None, masks, MASK_NEGINF)
+            yield
             x, st = self._fz_dense_res(W, a, k + '.ao', x, None, None, 1e-5)
+            yield
             h = self._fz_proj(W, x, st, k + '.n2', k + '.ff1', 1e-5, ACT_GELU)
+            yield
             x, st = self._fz_dense_res(W, h, k + '.ff2', x, None, None, 1e-5, want_stats=i + 1 < cfg.num_pano_layers)
+            yield
         return x
 
     def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs, final_aux=None):
@@ -810,32 +898,11 @@ class GlocalTextPathNavCMT(nn.Module):
 
     def _x_layers_two_streams(self, W, kv, tm, g, v, gmask, vmask, dists, final_aux=None):
         """Global branch on the current stream, local branch on the side stream, advanced in turn (no-grad mode only)."""
-        cur = torch.cuda.current_stream()
-        if self._side_stream is None:
-            self._side_stream = {}
-        side = self._side_stream.get(cur.cuda_stream)
-        if side is None:
-            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
-        side.wait_stream(cur)
         fa = final_aux or [None, None]
-        gens = [(side, self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',), final_aux=[fa[1]])),
-                (cur, self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',), final_aux=[fa[0]]))]
-        res, live = [None, None], [0, 1]
-        self._fork_depth += 1
-        try:
-            while live:
-                for i in list(live):
-                    with torch.cuda.stream(gens[i][0]):
-                        try:
-                            next(gens[i][1])
-                        except StopIteration as e:
-                            res[i] = e.value[0]
-                            live.remove(i)
-        finally:
-            self._fork_depth -= 1
-        cur.wait_stream(side)
-        res[0].record_stream(cur)
-        return res[1], res[0]
+        rl, rg = self._run_interleaved(self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',), final_aux=[fa[1]]),
+                                       self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',), final_aux=[fa[0]]))
+        rl[0].record_stream(torch.cuda.current_stream())
+        return rg[0], rl[0]
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
         p = self.config.hidden_dropout_prob if self.training else 0.0

@@ -230,6 +230,10 @@ def _attn_ref(q, k, v, nh, kmask, mode, dists, sw, sb, scale=0.125):
 @pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [
     (8, 12, 20, 80, 1, False), (8, 12, 38, 38, 1, False), (8, 12, 20, 20, 1, True), (4, 12, 36, 36, 2, False),
     (4, 2, 108, 108, 3, False), (2, 2, 720, 720, 3, False), (2, 12, 100, 250, 1, False), (3, 12, 1, 5, 0, False),
+    # the short-key kernel (Nk <= 128: K fragments straight from global memory, transposing V reads): every tile count,
+    # partial last tiles, two query blocks, pair distances with rows that are / are not 16-byte aligned
+    (2, 12, 70, 127, 1, True), (2, 12, 5, 33, 2, False), (2, 12, 64, 128, 3, False), (2, 12, 17, 22, 1, True),
+    (2, 12, 100, 100, 1, True), (3, 2, 36, 56, 1, False), (2, 12, 130, 96, 0, False),
 ])
 def test_attention(K, dtype, B, nh, Nq, Nk, mode, sprel):
     H = nh * 64
