@@ -168,19 +168,32 @@ const unsigned long long* dsrg_dropout_offset_ptr();
 // Stage the feature projection Wf [H,F] transposed into LDS (WT[k*HS + h]) with NT threads.  Eight loads are issued
 // before the first LDS store: a plain `WT[..] = Wf[j]` loop with a run-time trip count compiles to load / wait / store
 // per iteration, i.e. one memory latency per 4 bytes per thread (21 in a row for H*F = 5376 and 256 threads).
+// Staged as 16-byte loads of the flat [H*F] array (H % 4 == 0, so H*F is a multiple of 4 and every piece is whole): 2-3 loads
+// and 8-12 LDS stores per thread instead of 16 + 16 four-byte ones; j / F is a multiply-high by ceil(2^32 / F) (exact for
+// j < 2^28), not the ~35-instruction run-time division.  The token-embedding kernels are VALU-bound (rocprofv3 SQ counters,
+// round 3: 886 vector instructions per row, ~190 of them this staging).
 template <int NT>
 __device__ __forceinline__ void stage_wt(float* WT, const float* __restrict__ Wf, int H, int F, int HS, int tid) {
-  const int n = H * F;
-  for (int j0 = tid; j0 < n; j0 += NT * 8) {
-    float v[8];
+  const int n4 = (H * F) >> 2;
+  const unsigned magic = F > 1 ? 0xFFFFFFFFu / (unsigned)F + 1u : 0u;
+  const float4* __restrict__ W4 = reinterpret_cast<const float4*>(Wf);
+  constexpr int UB = 12;       // pieces per thread and round: one round (one memory latency) for H*F <= 48 NT floats
+  for (int j0 = tid; j0 < n4; j0 += NT * UB) {
+    float4 v[UB];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = Wf[min(j0 + u * NT, n - 1)];
+    for (int u = 0; u < UB; ++u) v[u] = W4[min(j0 + u * NT, n4 - 1)];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int j = j0 + u * NT;
-      if (j < n) {
-        const int h = j / F, k = j - h * F;
-        WT[k * HS + h] = v[u];
+    for (int u = 0; u < UB; ++u) {
+      const int j4 = j0 + u * NT;
+      if (j4 < n4) {
+        const int j = j4 << 2;
+        int h = F > 1 ? (int)__umulhi((unsigned)j, magic) : j, k = j - h * F;
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          WT[k * HS + h] = e[t];
+          if (++k == F) { k = 0; ++h; }
+        }
       }
     }
   }

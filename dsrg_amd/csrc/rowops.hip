@@ -2,6 +2,8 @@
 // One 64-lane wave owns one row; statistics by wave reduction in fp32.  HBM-bound (rows are read once,
 // 8/16 bytes per lane), so the only rules that matter are coalescing and enough waves in flight.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -166,6 +168,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs a) {
   }
 }
 
+#ifdef DSRG_EMBED_STAMPS   // diagnostic build only (tools/micro/embed_time.py --stamps): per-workgroup s_memtime stamps
+__device__ unsigned long long g_embed_stamps[4096 * 8];
+#define EMBED_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_embed_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EMBED_STAMP(i) do {} while (0)
+#endif
 struct EmbedIdx { const void* p; int kind, stride, div; };
 struct EmbedArgs {
   const void* base; int ldb;
@@ -179,35 +187,63 @@ struct EmbedArgs {
 };
 
 __device__ __forceinline__ int embed_index(const EmbedIdx& ix, int row) {
-  const size_t o = (size_t)(row / ix.div) * ix.stride;
+  const size_t o = (size_t)(ix.div == 1 ? row : row / ix.div) * ix.stride;      // (uniform branch: the division is ~35 instructions)
   if (ix.kind == DSRG_IDX_I32) return reinterpret_cast<const int32_t*>(ix.p)[o];
   if (ix.kind == DSRG_IDX_I64) return (int)reinterpret_cast<const int64_t*>(ix.p)[o];
   return (int)reinterpret_cast<const float*>(ix.p)[o];      // class id carried as a float feature column
 }
 
-// 16 waves per workgroup, one row per wave.  The feature projection Wf [H,F] (F <= 16) is staged once per workgroup,
+// 8 waves per workgroup, one row per wave (16 left 104 of the 256 CUs idle at the nav-step's 1280-2432 rows, and the kernel is
+// VALU-bound: four waves per SIMD on 152 CUs took 14.7 us for the 2432 viewpoint tokens).  The feature projection Wf [H,F] (F <= 16) is staged once per workgroup,
 // transposed, in LDS (WT[k][h], rows padded by 4 floats) so that a lane's 4 output columns are one ds_read_b128 per k.
 // The step is latency-bound (a few KB per row), so every independent global load of the row - features, indices,
 // base row, both table rows - is issued before the staging barrier and the row's arithmetic starts with all of
 // them in flight.
-constexpr int EWAVES = 16;
+constexpr int EWAVES = 4;
 
-template <typename T>
-__global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
+// LayerNorm of a row held as NV float4 per lane with gamma / beta already in registers (same arithmetic, in the same order, as
+// ln_row); ok[i]: this lane's chunk i lies inside the row.
+template <int NV>
+__device__ __forceinline__ void ln_row_pre(float4 (&v)[NV], const bool (&ok)[NV], int H, const float4 (&g)[NV], const float4 (&b)[NV], float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (ok[i]) s += v[i].x + v[i].y + v[i].z + v[i].w;
+  const float mean = wave_sum(s) / (float)H;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (ok[i]) {
+      float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      ss += a * a + bb * bb + c * c + d * d;
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    v[i] = make_float4((v[i].x - mean) * rstd * g[i].x + b[i].x, (v[i].y - mean) * rstd * g[i].y + b[i].y,
+                       (v[i].z - mean) * rstd * g[i].z + b[i].z, (v[i].w - mean) * rstd * g[i].w + b[i].w);
+}
+
+// NV = float4 chunks per lane (ceil(H / 256)), a template parameter (as in layernorm_kernel): EVERY global load of the row -
+// features, indices, base row, table rows, and the per-column vectors (projection bias, both LayerNorms' gamma / beta) - is
+// issued before the staging barrier, unconditionally per lane (columns clamped).  In-kernel stamps (round 3,
+// profiles/r03s_embed_stamps.txt): with the bias load inside each chunk's `if (c < H)` and gamma / beta loaded inside the
+// LayerNorms, a workgroup spent 8.3 k cycles in the projection and 1.9 k in the first LayerNorm waiting for five exposed
+// memory latencies; the kernel took 13-15 us for 1280-2432 rows against 4 us for a plain LayerNorm of the same rows.
+template <typename T, int NV>
+__global__ __launch_bounds__(64 * EWAVES) void embed_ln_kernel(const EmbedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float WT[];
+  EMBED_STAMP(0);
   // the whole launch record in one batch of scalar loads (the compiler otherwise sinks them into four dependent rounds)
   asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
                "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
                "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
   asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int H = a.H, nv = (H + 255) / 256, HS = H + 4;
+  const int H = a.H, HS = H + 4;
   const int row = blockIdx.x * EWAVES + wave;
   const bool live = row < a.M;
   const T* base = reinterpret_cast<const T*>(a.base);
-  // Loads first, use later: rows past M and columns past H read a clamped (valid) address, and nothing consumes a
-  // loaded value until every load of the row has been issued (a `cond ? load : 0` or an add right behind each load
-  // made the compiler wait for it before issuing the next: ~12 memory latencies in a row in the first version's ISA).
   const int rowc = min(row, a.M - 1);
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const T* brow = base ? base + (size_t)rowc * a.ldb : nullptr;
@@ -218,62 +254,216 @@ __global__ __launch_bounds__(1024) void embed_ln_kernel(const EmbedArgs a) {
     else if (t < l0 + l1) brow = reinterpret_cast<const T*>(a.base2) + ((size_t)eb * a.seg_No + (t - l0)) * a.ldb2;
     else brow = nullptr;
   }
+  int cc[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { cc[i] = min((i * 64 + lane) * 4, H - 4); ok[i] = (i * 64 + lane) * 4 < H; }
   // the row's features: ONE load (lane k holds feature k), broadcast below - F conditional loads were F latencies in a row
   const float fl = a.feat ? a.feat[(size_t)rowc * a.ldf + min(lane, a.F - 1)] : 0.f;
   const int i1 = a.E1 ? embed_index(a.i1, rowc) : 0, i2 = a.E2 ? embed_index(a.i2, rowc) : 0;
-  float4 lb[MAXV], l1[MAXV], l2[MAXV], lv[MAXV];
+  typename Raw4<T>::type rb[NV];
+  float4 l1[NV], l2[NV], lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    if (i < nv) {                                   // uniform
-      const int cc = min((i * 64 + lane) * 4, H - 4);
-      lb[i] = brow ? ld4(brow + cc) : z4;
-      l1[i] = a.E1 ? *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + cc) : z4;
-      l2[i] = a.E2 ? *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + cc) : z4;
-      lv[i] = a.vec ? *reinterpret_cast<const float4*>(a.vec + cc) : z4;
-    }
-  }
-  float4 add[MAXV];
+  for (int i = 0; i < NV; ++i) l1[i] = l2[i] = lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = z4;
+  // (every condition below is uniform: a scalar branch around a batch of loads, nothing waits inside it)
+  if (brow) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    add[i] = z4;
-    if (live && i < nv && (i * 64 + lane) * 4 < H) add[i] = f4add(f4add(lb[i], l1[i]), f4add(l2[i], lv[i]));
+    for (int i = 0; i < NV; ++i) rb[i] = raw_ld4(brow + cc[i]);
   }
+  if (a.E1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) l1[i] = *reinterpret_cast<const float4*>(a.E1 + (size_t)i1 * H + cc[i]);
+  }
+  if (a.E2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) l2[i] = *reinterpret_cast<const float4*>(a.E2 + (size_t)i2 * H + cc[i]);
+  }
+  if (a.vec) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lv[i] = *reinterpret_cast<const float4*>(a.vec + cc[i]);
+  }
+  if (a.feat && a.bf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bfv[i] = *reinterpret_cast<const float4*>(a.bf + cc[i]);
+  }
+  if (a.feat && a.lnf_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g1[i] = *reinterpret_cast<const float4*>(a.lnf_g + cc[i]); b1[i] = *reinterpret_cast<const float4*>(a.lnf_b + cc[i]); }
+  }
+  if (a.lno_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g2[i] = *reinterpret_cast<const float4*>(a.lno_g + cc[i]); b2[i] = *reinterpret_cast<const float4*>(a.lno_b + cc[i]); }
+  }
+  EMBED_STAMP(1);
   if (a.feat) {
     stage_wt<64 * EWAVES>(WT, a.Wf, H, a.F, HS, threadIdx.x);
     __syncthreads();
   }
+  EMBED_STAMP(2);
   if (!live) return;
-  float4 v[MAXV];
+  float4 v[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NV; ++i) v[i] = z4;
   if (a.feat) {
     float f[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) f[k] = k < a.F ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fl), k)) : 0.f;
+    // Branch-free over 8 or 16 features (rows of WT past F are read clamped and meet f[k] = 0): the LDS reads of a chunk go
+    // out together instead of one round trip per k
+    auto project = [&](auto kn_tag) {
+      constexpr int KN = decltype(kn_tag)::value;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (i < nv && c < H) {
-        float4 o = a.bf ? *reinterpret_cast<const float4*>(a.bf + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < NV; ++i) {
+        float4 o = bfv[i];
+        float4 w[KN];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < a.F) {
-            const float4 w = *reinterpret_cast<const float4*>(&WT[k * HS + c]);
-            o.x = fmaf(w.x, f[k], o.x); o.y = fmaf(w.y, f[k], o.y); o.z = fmaf(w.z, f[k], o.z); o.w = fmaf(w.w, f[k], o.w);
-          }
+        for (int k = 0; k < KN; ++k) w[k] = *reinterpret_cast<const float4*>(&WT[min(k, a.F - 1) * HS + cc[i]]);
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+          o.x = fmaf(w[k].x, f[k], o.x); o.y = fmaf(w[k].y, f[k], o.y); o.z = fmaf(w[k].z, f[k], o.z); o.w = fmaf(w[k].w, f[k], o.w);
+        }
         v[i] = o;
       }
-    }
-    if (a.lnf_g) ln_row<MAXV>(v, nv, lane, H, a.lnf_g, a.lnf_b, a.eps);
+    };
+    if (a.F == 7) project(std::integral_constant<int, 7>{});            // (the reference's position features: 7 and 14 wide)
+    else if (a.F <= 8) project(std::integral_constant<int, 8>{});
+    else if (a.F == 14) project(std::integral_constant<int, 14>{});
+    else project(std::integral_constant<int, 16>{});
+    EMBED_STAMP(3);
+    if (a.lnf_g) ln_row_pre<NV>(v, ok, H, g1, b1, a.eps);
   }
+  EMBED_STAMP(4);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) v[i] = f4add(add[i], v[i]);
-  if (a.lno_g) ln_row<MAXV>(v, nv, lane, H, a.lno_g, a.lno_b, a.eps);
+  for (int i = 0; i < NV; ++i) {
+    const float4 lb = brow ? raw4(rb[i]) : z4;
+    v[i] = f4add(f4add(f4add(lb, l1[i]), f4add(l2[i], lv[i])), v[i]);
+  }
+  if (a.lno_g) ln_row_pre<NV>(v, ok, H, g2, b2, a.eps);
+  EMBED_STAMP(5);
   T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (i < nv && c < H) st4(out + (size_t)row * a.ldo + c, v[i]);
+  for (int i = 0; i < NV; ++i)
+    if (ok[i]) st4(out + (size_t)row * a.ldo + cc[i], v[i]);
+  EMBED_STAMP(6);
+}
+
+// Register-resident projection (the reference's position features: F = 7 or 14): the kernel above re-reads the whole staged
+// W^T from LDS for every row - 43 KB per viewpoint token, 9.5 rows per CU - and is LDS-bandwidth-bound there (stamps: 8.4 k of a
+// workgroup's 17 k cycles; the rest is one memory latency for the row and one for the staging).  Here a lane keeps the weights
+// of ITS columns in registers: columns c..c+3 of chunk i are rows c..c+3 of Wf [H,F], i.e. 4F contiguous floats = F float4 as
+// they lie (no transposition, no LDS, no barrier), read once per wave and used for ER rows.  Every global load of the wave -
+// weights, per-column vectors, the ER rows' base / feature / table rows - is issued up front.
+// Element (hh, k) of a lane's chunk is float hh*F + k of its F float4.
+constexpr int ER = 3;          // rows per wave: 2432 viewpoint tokens = 203 workgroups of 4 waves (one round on 256 CUs)
+template <typename T, int NV, int F>
+__global__ __launch_bounds__(256) void embed_ln_regw_kernel(const EmbedArgs a) {
+  asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
+               "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
+               "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
+  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = a.H;
+  const int row0 = (blockIdx.x * 4 + wave) * ER;
+  if (row0 >= a.M) return;                                   // wave-uniform; no barrier in this kernel
+  const T* base = reinterpret_cast<const T*>(a.base);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cc[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { cc[i] = min((i * 64 + lane) * 4, H - 4); ok[i] = (i * 64 + lane) * 4 < H; }
+  // ---- per row: indices and features first (the table rows depend on the indices)
+  int rowc[ER], i1[ER], i2[ER];
+  float fl[ER];
+  const T* brow[ER];
+#pragma unroll
+  for (int r = 0; r < ER; ++r) {
+    rowc[r] = min(row0 + r, a.M - 1);
+    fl[r] = a.feat[(size_t)rowc[r] * a.ldf + min(lane, F - 1)];
+    i1[r] = a.E1 ? embed_index(a.i1, rowc[r]) : 0;
+    i2[r] = a.E2 ? embed_index(a.i2, rowc[r]) : 0;
+    brow[r] = base ? base + (size_t)rowc[r] * a.ldb : nullptr;
+    if (a.seg_T > 0) {
+      const int eb = rowc[r] / a.seg_T, t = rowc[r] - eb * a.seg_T;
+      const int l0 = (int)a.lens0[eb], l1 = (int)a.lens1[eb];
+      if (t < l0) brow[r] = base + ((size_t)eb * a.seg_V + t) * a.ldb;
+      else if (t < l0 + l1) brow[r] = reinterpret_cast<const T*>(a.base2) + ((size_t)eb * a.seg_No + (t - l0)) * a.ldb2;
+      else brow[r] = nullptr;
+    }
+  }
+  // ---- weights of this lane's columns, per-column vectors
+  float4 w[NV][F];
+  const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wf);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int k = 0; k < F; ++k) w[i][k] = W4[(size_t)(cc[i] >> 2) * F + k];
+  float4 lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = z4;
+  if (a.vec) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lv[i] = *reinterpret_cast<const float4*>(a.vec + cc[i]);
+  }
+  if (a.bf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) bfv[i] = *reinterpret_cast<const float4*>(a.bf + cc[i]);
+  }
+  if (a.lnf_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g1[i] = *reinterpret_cast<const float4*>(a.lnf_g + cc[i]); b1[i] = *reinterpret_cast<const float4*>(a.lnf_b + cc[i]); }
+  }
+  if (a.lno_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g2[i] = *reinterpret_cast<const float4*>(a.lno_g + cc[i]); b2[i] = *reinterpret_cast<const float4*>(a.lno_b + cc[i]); }
+  }
+  // ---- the rows' base and table rows
+  typename Raw4<T>::type rb[ER][NV];
+  float4 l1[ER][NV], l2[ER][NV];
+#pragma unroll
+  for (int r = 0; r < ER; ++r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) l1[r][i] = l2[r][i] = z4;
+    if (brow[r]) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) rb[r][i] = raw_ld4(brow[r] + cc[i]);
+    }
+    if (a.E1) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) l1[r][i] = *reinterpret_cast<const float4*>(a.E1 + (size_t)i1[r] * H + cc[i]);
+    }
+    if (a.E2) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) l2[r][i] = *reinterpret_cast<const float4*>(a.E2 + (size_t)i2[r] * H + cc[i]);
+    }
+  }
+  T* out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int r = 0; r < ER; ++r) {
+    if (row0 + r >= a.M) break;                              // wave-uniform
+    float f[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) f[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fl[r]), k));
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float o[4] = {bfv[i].x, bfv[i].y, bfv[i].z, bfv[i].w};
+      const float* wf = reinterpret_cast<const float*>(&w[i][0]);      // (compile-time indices: stays in registers)
+#pragma unroll
+      for (int k = 0; k < F; ++k)                            // k outermost: the same fma chain per column as the staged kernel
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) o[hh] = fmaf(wf[hh * F + k], f[k], o[hh]);
+      v[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (a.lnf_g) ln_row_pre<NV>(v, ok, H, g1, b1, a.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 lb = brow[r] ? raw4(rb[r][i]) : z4;
+      v[i] = f4add(f4add(f4add(lb, l1[r][i]), f4add(l2[r][i], lv[i])), v[i]);
+    }
+    if (a.lno_g) ln_row_pre<NV>(v, ok, H, g2, b2, a.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) st4(out + (size_t)(row0 + r) * a.ldo + cc[i], v[i]);
   }
 }
 
@@ -746,6 +936,12 @@ extern "C" int dsrg_layernorm_fwd(const void* x, int ldx, const void* residual, 
   return dsrg_layernorm_fwd_grouped(&p, 1, H, eps, in_dtype, out_dtype, stream);
 }
 
+#ifdef DSRG_EMBED_STAMPS
+extern "C" int dsrg_debug_embed_stamps(void* host_dst, int nbytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_embed_stamps), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, int ldf, int F, const float* Wf, const float* bf,
                                  const float* lnf_gamma, const float* lnf_beta,
                                  const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
@@ -771,7 +967,7 @@ extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base
   DSRG_CHECK(ok_dtype(dtype), "dsrg_embed_ln_fwd: bad dtype %d", dtype);
   DSRG_CHECK(out && M >= 0, "dsrg_embed_ln_fwd: null out");
   DSRG_CHECK(H > 0 && H <= 1024 && H % 64 == 0, "dsrg_embed_ln_fwd: H=%d must be a multiple of 64 and <= 1024", H);
-  DSRG_CHECK(!feat || (Wf && F >= 1 && F <= 16 && ldf >= F), "dsrg_embed_ln_fwd: feature term needs Wf and 1 <= F <= 16");
+  DSRG_CHECK(!feat || (Wf && F >= 1 && F <= 16 && ldf >= F && ((uintptr_t)Wf & 15) == 0), "dsrg_embed_ln_fwd: feature term needs a 16-byte aligned Wf and 1 <= F <= 16");
   DSRG_CHECK((!E1 || idx1) && (!E2 || idx2), "dsrg_embed_ln_fwd: embedding table without indices");
   DSRG_CHECK((!E1 || (idx1_kind >= DSRG_IDX_I32 && idx1_kind <= DSRG_IDX_F32 && idx1_stride >= 1 && idx1_div >= 1)) &&
                  (!E2 || (idx2_kind >= DSRG_IDX_I32 && idx2_kind <= DSRG_IDX_F32 && idx2_stride >= 1 && idx2_div >= 1)),
@@ -787,10 +983,37 @@ extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + EWAVES - 1) / EWAVES), block(64 * EWAVES);
   const size_t lds = feat ? (size_t)F * (H + 4) * sizeof(float) : 0;     // <= 16 * 1028 * 4 = 65,792 B
-  DSRG_SET_MAX_LDS_ONCE(&embed_ln_kernel<float>, 66 * 1024);
-  DSRG_SET_MAX_LDS_ONCE(&embed_ln_kernel<bf16_t>, 66 * 1024);
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((embed_ln_kernel<float>), grid, block, lds, s, a);
-  else hipLaunchKernelGGL((embed_ln_kernel<bf16_t>), grid, block, lds, s, a);
+  // position features of the reference's widths on 768- / 128-wide rows: weights in registers, no LDS (embed_ln_regw_kernel)
+  static const bool regw_on = []() { const char* e = getenv("DSRG_EMBED_REGW"); return !(e && e[0] == '0'); }();
+  if (regw_on && feat && (F == 7 || F == 14) && (H == 768 || H == 128)) {
+    dim3 g2((M + 4 * ER - 1) / (4 * ER)), b2(256);
+#define DSRG_REGW_LAUNCH(T_)                                                                               \
+    do {                                                                                                   \
+      if (H == 768 && F == 14) hipLaunchKernelGGL((embed_ln_regw_kernel<T_, 3, 14>), g2, b2, 0, s, a);      \
+      else if (H == 768) hipLaunchKernelGGL((embed_ln_regw_kernel<T_, 3, 7>), g2, b2, 0, s, a);             \
+      else if (F == 14) hipLaunchKernelGGL((embed_ln_regw_kernel<T_, 1, 14>), g2, b2, 0, s, a);             \
+      else hipLaunchKernelGGL((embed_ln_regw_kernel<T_, 1, 7>), g2, b2, 0, s, a);                           \
+    } while (0)
+    if (dtype == DSRG_F32) DSRG_REGW_LAUNCH(float);
+    else DSRG_REGW_LAUNCH(bf16_t);
+#undef DSRG_REGW_LAUNCH
+    DSRG_LAUNCH_CHECK("dsrg_embed_ln_fwd");
+    return DSRG_OK;
+  }
+#define DSRG_EMBED_LAUNCH(T_, NV_)                                                      \
+  do {                                                                                  \
+    DSRG_SET_MAX_LDS_ONCE((&embed_ln_kernel<T_, NV_>), 66 * 1024);                      \
+    hipLaunchKernelGGL((embed_ln_kernel<T_, NV_>), grid, block, lds, s, a);             \
+  } while (0)
+  const int nvc = (H + 255) / 256;
+  if (dtype == DSRG_F32) {
+    if (nvc == 1) DSRG_EMBED_LAUNCH(float, 1); else if (nvc == 2) DSRG_EMBED_LAUNCH(float, 2);
+    else if (nvc == 3) DSRG_EMBED_LAUNCH(float, 3); else DSRG_EMBED_LAUNCH(float, 4);
+  } else {
+    if (nvc == 1) DSRG_EMBED_LAUNCH(bf16_t, 1); else if (nvc == 2) DSRG_EMBED_LAUNCH(bf16_t, 2);
+    else if (nvc == 3) DSRG_EMBED_LAUNCH(bf16_t, 3); else DSRG_EMBED_LAUNCH(bf16_t, 4);
+  }
+#undef DSRG_EMBED_LAUNCH
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_fwd");
   return DSRG_OK;
 }

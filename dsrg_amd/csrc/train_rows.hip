@@ -662,6 +662,7 @@ extern "C" int dsrg_embed_ln_bwd(const dsrg_embed_bwd_args_t* args, void* stream
   DSRG_CHECK(okdt(a.dtype) && a.dout && a.M >= 0, "dsrg_embed_ln_bwd: bad dtype or null dout");
   DSRG_CHECK(a.H > 0 && a.H <= 1024 && a.H % 64 == 0, "dsrg_embed_ln_bwd: H=%d must be a multiple of 64 and <= 1024", a.H);
   DSRG_CHECK(!a.feat || (a.Wf && a.dWf && a.F >= 1 && a.F <= 16 && a.ldf >= a.F && (!a.bf == !a.dbf)), "dsrg_embed_ln_bwd: feature term needs Wf, dWf, 1 <= F <= 16");
+  DSRG_CHECK(!a.feat || ((uintptr_t)a.Wf & 15) == 0, "dsrg_embed_ln_bwd: Wf must be 16-byte aligned");
   DSRG_CHECK((!a.lnf_gamma || (a.feat && a.lnf_beta && a.dlnf_gamma && a.dlnf_beta)) && (!a.lno_gamma || (a.lno_beta && a.dlno_gamma && a.dlno_beta)),
              "dsrg_embed_ln_bwd: LayerNorm operands / gradients incomplete");
   DSRG_CHECK((!a.E1 || a.idx1) && (!a.E2 || a.idx2) && (!a.dE1 || a.E1) && (!a.dE2 || a.E2) && (!a.vec == !a.dvec), "dsrg_embed_ln_bwd: table / index / gradient mismatch");

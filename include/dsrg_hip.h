@@ -244,7 +244,7 @@ int dsrg_layernorm_fwd_grouped(const dsrg_ln_problem_t* problems /*host*/, int n
  *   panorama tokens (img + LN(loc_linear) + nav_type + token_type[1] -> LN), :719-723;
  *   graph-map tokens (img + step embedding + LN(Linear(7))), :753-755;
  *   viewpoint tokens (img + LN(Linear(14))), :769.
- * feat is fp32 [M,F] (ldf), F <= 16; Wf is fp32 [H,F] (the nn.Linear layout); E1/E2/vec/gammas/betas fp32;
+ * feat is fp32 [M,F] (ldf), F <= 16; Wf is fp32 [H,F] (the nn.Linear layout, 16-byte aligned); E1/E2/vec/gammas/betas fp32;
  * base/out `dtype`.  lnf_* NULL => no LayerNorm on the feature term; lno_* NULL => no output LayerNorm.
  * Row r takes table index idx[(r / div) * stride], read as int32, int64 or as a float that carries a class id
  * (the reference keeps the object class in the last feature column, :701, and repeats the per-view nav type over
