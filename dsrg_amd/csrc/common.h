@@ -168,10 +168,10 @@ const unsigned long long* dsrg_dropout_offset_ptr();
 // Stage the feature projection Wf [H,F] transposed into LDS (WT[k*HS + h]) with NT threads.  Eight loads are issued
 // before the first LDS store: a plain `WT[..] = Wf[j]` loop with a run-time trip count compiles to load / wait / store
 // per iteration, i.e. one memory latency per 4 bytes per thread (21 in a row for H*F = 5376 and 256 threads).
-// Staged as 16-byte loads of the flat [H*F] array (H % 4 == 0, so H*F is a multiple of 4 and every piece is whole): 2-3 loads
-// and 8-12 LDS stores per thread instead of 16 + 16 four-byte ones; j / F is a multiply-high by ceil(2^32 / F) (exact for
-// j < 2^28), not the ~35-instruction run-time division.  The token-embedding kernels are VALU-bound (rocprofv3 SQ counters,
-// round 3: 886 vector instructions per row, ~190 of them this staging).
+// Staged as 16-byte loads of the flat [H*F] array (H % 4 == 0, so H*F is a multiple of 4 and every piece is whole), all of a
+// thread's pieces in flight at once; j / F is a multiply-high by ceil(2^32 / F) (exact for j < 2^28), not the ~35-instruction
+// run-time division.  (Round 3 stamps: the staging's own cost is small next to the memory latency in front of it; the kernel
+// that used it for every launch was LDS-read-bound in its projection loop - see embed_ln_regw_kernel in rowops.hip.)
 template <int NT>
 __device__ __forceinline__ void stage_wt(float* WT, const float* __restrict__ Wf, int H, int F, int HS, int tid) {
   const int n4 = (H * F) >> 2;

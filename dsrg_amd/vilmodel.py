@@ -189,6 +189,9 @@ class GlocalTextPathNavCMT(nn.Module):
         self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
         # panorama call: view chain and object-token chain captured launch by launch in turn (A/B in DESIGN.md)
         self.interleave_pano = os.environ.get('DSRG_INTERLEAVE_PANO', '1') == '1'
+        self.split_big = int(os.environ.get('DSRG_SPLIT_BIG', '2'))      # the longer branch as up to this many part-batch chains (_x_layers_two_streams; 1 = whole;
+                                                                         # 3 or 4, i.e. four or five concurrent chains, is 15-25 % SLOWER than 2)
+        self.split_ratio = float(os.environ.get('DSRG_SPLIT_RATIO', '1.75'))
         self._fold = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
 
@@ -536,43 +539,45 @@ class GlocalTextPathNavCMT(nn.Module):
             except StopIteration as e:
                 return e.value
 
-    def _side(self, cur):
+    def _side(self, cur, k=0):
         if self._side_stream is None:
             self._side_stream = {}
-        side = self._side_stream.get(cur.cuda_stream)          # one side stream per calling stream
+        key = (cur.cuda_stream, k)
+        side = self._side_stream.get(key)          # side streams per calling stream
         if side is None:
-            side = self._side_stream[cur.cuda_stream] = torch.cuda.Stream()
+            side = self._side_stream[key] = torch.cuda.Stream()
         return side
 
-    def _run_interleaved(self, side_gen, main_gen):
-        """Two independent launch chains (generators that yield between launches): `side_gen` on the side stream, `main_gen` on
-        the current one, advanced in turn so that their nodes enter a captured HIP graph interleaved - hipGraphLaunch submits
-        kernel nodes in creation order, and a chain captured as a whole before the other one delays the other's first launch
-        by its own submission time.  No-grad mode only.  -> (side result, main result); the current stream has waited for the
-        side stream on return."""
+    def _run_interleaved(self, *gens):
+        """Independent launch chains (generators that yield between launches): the LAST one on the current stream, the others
+        on side streams, advanced in turn so that their nodes enter a captured HIP graph interleaved - hipGraphLaunch submits
+        kernel nodes in creation order, and a chain captured as a whole before the others delays their first launches by its
+        own submission time.  No-grad mode only.  -> the chains' results, in order; the current stream has waited for the
+        side streams on return."""
         cur = torch.cuda.current_stream()
-        side = self._side(cur)
-        side.wait_stream(cur)
-        gens = [(side, side_gen), (cur, main_gen)]
-        res, live = [None, None], [0, 1]
+        streams = [self._side(cur, k) for k in range(len(gens) - 1)] + [cur]
+        for st in streams[:-1]:
+            st.wait_stream(cur)
+        res, live = [None] * len(gens), list(range(len(gens)))
         self._fork_depth += 1
         try:
             while live:
                 for i in list(live):
-                    with torch.cuda.stream(gens[i][0]):
+                    with torch.cuda.stream(streams[i]):
                         try:
-                            next(gens[i][1])
+                            next(gens[i])
                         except StopIteration as e:
                             res[i] = e.value
                             live.remove(i)
         finally:
             self._fork_depth -= 1
-        cur.wait_stream(side)
-        r = res[0]
-        for t in (r if isinstance(r, (tuple, list)) else (r,)):
-            if isinstance(t, torch.Tensor):
-                t.record_stream(cur)
-        return res[0], res[1]
+        for st in streams[:-1]:
+            cur.wait_stream(st)
+        for r in res[:-1]:
+            for t in (r if isinstance(r, (tuple, list)) else (r,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+        return res
 
     def _fork(self, fn):
         """Run fn() on the model's side stream (no-grad mode only) and return join() -> its result.  The object-token
@@ -783,7 +788,7 @@ class GlocalTextPathNavCMT(nn.Module):
             yield
         return x
 
-    def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs, final_aux=None):
+    def _x_layers_fused_gen(self, W, kv, txt_masks, feats, masks, dists, brs, final_aux=None, final_out=None):
         """(generator: yields after every launch, returns the result - see _x_layers_gen)
         _x_layers without its 3 LayerNorm launches per layer and branch (inference).  A post-LN sub-block leaves its
         UN-normalised sum y (compute dtype) plus per-row partial statistics written by the same GEMM launch; the projections
@@ -850,7 +855,8 @@ class GlocalTextPathNavCMT(nn.Module):
             if i == nl - 1:
                 z = dense_res('.ff2', inter, None, out_f32=True)
                 yield
-                return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd, aux=final_aux)
+                return K.layernorm_grouped([(z[j], W[ks[j] + '.fln.g'], W[ks[j] + '.fln.b'], None) for j in range(n)], eps, cd, aux=final_aux,
+                                           outs=final_out)
             st = new_stats()
             y = dense_res('.ff2', inter, st)
             yield
@@ -867,14 +873,15 @@ class GlocalTextPathNavCMT(nn.Module):
             except StopIteration as e:
                 return e.value
 
-    def _x_layers_gen(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l'), final_aux=None):
+    def _x_layers_gen(self, W, kv, txt_masks, feats, masks, dists, brs=('g', 'l'), final_aux=None, final_out=None):
         """_x_layers as a generator that yields between its launches and returns the result: the two-stream schedule
         (_x_layers_two_streams) advances the global and the local branch in turn, so that their nodes enter the captured HIP
         graph interleaved - hipGraphLaunch submits kernel nodes in creation order, and a branch captured as a whole after the
         other one starts several hundred microseconds late."""
         cfg = self.config
         if self.fuse_ln and not torch.is_grad_enabled() and not self.training and cfg.hidden_size % 64 == 0 and cfg.hidden_size <= 1024:
-            return (yield from self._x_layers_fused_gen(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs, final_aux))
+            return (yield from self._x_layers_fused_gen(W, kv, txt_masks, [f.contiguous() for f in feats], masks, dists, brs, final_aux, final_out))
+        assert final_out is None, 'final_out: LayerNorm-fused inference schedule only'
         H, nh, eps, nl = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps, cfg.num_x_layers
         n = len(brs)
         sw, sb = (W['sprel.w'], W['sprel.b']) if dists is not None else (None, None)
@@ -897,11 +904,35 @@ class GlocalTextPathNavCMT(nn.Module):
         return feats
 
     def _x_layers_two_streams(self, W, kv, tm, g, v, gmask, vmask, dists, final_aux=None):
-        """Global branch on the current stream, local branch on the side stream, advanced in turn (no-grad mode only)."""
+        """Global branch on the current stream, local branch on side streams, advanced in turn (no-grad mode only).
+        split_big (inference, LayerNorm-fused schedule): when one branch has split_ratio (1.75) times the other's tokens per
+        episode - R2R's 38 viewpoint tokens against 20 graph nodes, REVERIE's 58 against 20, 100 graph nodes against 38 - the
+        larger one runs as two chains over the halves of the episode batch (episodes are independent in every launch), so
+        that three chains of comparable length share the chip to the end instead of the long one running alone, on a
+        two-thirds-empty chip, once the short one is through (same box: c3 1.380 -> 1.319 ms, c2 0.996 -> 0.991;
+        four parts: 1.26)."""
         fa = final_aux or [None, None]
+        B, G, Vp = g.shape[0], g.shape[1], v.shape[1]
+        big = 'l' if Vp >= G else 'g'
+        # number of chains of the longer branch: its rows over the shorter one's, rounded, at most split_big (2: with a third
+        # or fourth part - four or five concurrent chains - the step is 15-25 % slower: c3 1.33 -> 1.58 ms, c5 1.70 -> 1.92)
+        # and at least 8 episodes per chain
+        ns = min(self.split_big, int(max(G, Vp) / min(G, Vp) + 0.5), B // 8)
+        if ns > 1 and self._fuse_ok(self.config.hidden_size) and max(G, Vp) >= self.split_ratio * min(G, Vp):
+            cut = [(i * B + ns // 2) // ns for i in range(ns + 1)]          # episode ranges, sizes differing by at most one
+            x, xm, xa = (v, vmask, fa[1]) if big == 'l' else (g, gmask, fa[0])
+            xout = torch.empty_like(x)
+            part = lambda t, i: None if t is None else t[cut[i]:cut[i + 1]]
+            gens = [self._x_layers_gen(W, part(kv, i), part(tm, i), [part(x, i)], [part(xm, i)], part(dists, i), brs=(big,),
+                                       final_aux=[None if xa is None else (xa[0], part(xa[1], i), part(xa[2], i))], final_out=[part(xout, i)])
+                    for i in range(ns)]
+            if big == 'l':
+                gens.append(self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',), final_aux=[fa[0]]))
+                return self._run_interleaved(*gens)[ns][0], xout
+            gens.append(self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',), final_aux=[fa[1]]))
+            return xout, self._run_interleaved(*gens)[ns][0]
         rl, rg = self._run_interleaved(self._x_layers_gen(W, kv, tm, [v], [vmask], dists, brs=('l',), final_aux=[fa[1]]),
                                        self._x_layers_gen(W, kv, tm, [g], [gmask], dists, brs=('g',), final_aux=[fa[0]]))
-        rl[0].record_stream(torch.cuda.current_stream())
         return rg[0], rl[0]
 
     def _grouped_res_ln(self, W, ks, lin, ln, hs, res, eps):
@@ -969,7 +1000,7 @@ class GlocalTextPathNavCMT(nn.Module):
         # of the split schedule cost 3 %)
         if (self.split_branch_streams and not torch.is_grad_enabled() and self.overlap_streams
                 and max(G, Vp) <= self.split_max_ratio * min(G, Vp) and (torch.cuda.is_current_stream_capturing() or self.split_when_eager)):
-            if self.interleave_branches:
+            if self.interleave_branches or self.split_big > 1:
                 g, v = self._x_layers_two_streams(W, kv, tm, g, v, gmap_masks.contiguous(), vp_masks.contiguous(), dists, final_aux)
             else:
                 lj = self._fork(lambda: self._x_layers(W, kv, tm, [v], [vp_masks.contiguous()], dists, brs=('l',), final_aux=final_aux and [final_aux[1]])[0])
