@@ -21,11 +21,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP runtime knob, set before anything initialises HIP: hardware queues per process.  The captured nav-step forks into
-# up to three branches (view / object chains, global / local x-layers, heads / RMF); with HIP's default of 4 queues the
-# graph's branches share queues with the capture streams' (same box: 1.004 -> 0.997 ms per c2 step with 8, no change
-# beyond 8; profiles/r03t_ab_hw_queues.txt).  Reported in the JSON line as config.hw_queues; DSRG_HW_QUEUES overrides.
-os.environ['GPU_MAX_HW_QUEUES'] = os.environ.get('DSRG_HW_QUEUES', '8')
+# (GPU_MAX_HW_QUEUES is left at HIP's default of 4: 8 bought 0.7 % with two concurrent chains, but with the three-chain
+# schedule of this build any non-default value costs 35-110 %, profiles/r03t_ab_hw_queues.txt)
 
 import numpy as np
 import torch
@@ -741,7 +738,6 @@ def main():
                        if a.config == 'c2' else 'config %s' % a.config,
                        'name': a.config, 'episodes_per_gpu': B, 'txt_len': L, 'views': 36, 'objv2_per_view': O,
                        'graph_nodes': G, 'vp_tokens': Vp, 'reverie': reverie, 'launch': 'eager' if a.eager else 'hipgraph',
-                       'hw_queues': int(os.environ['GPU_MAX_HW_QUEUES']),
                        'text_kv': 'hoisted: one GEMM per episode batch (every %d steps), inside the timed region' % EPISODE_LEN,
                        'parallelism': 'replicas x%d (episode batch sharding, no collective)' % world},
             'algorithmic_gflop_per_episode_step': fl / 1e9,

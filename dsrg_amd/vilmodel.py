@@ -189,8 +189,9 @@ class GlocalTextPathNavCMT(nn.Module):
         self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
         # panorama call: view chain and object-token chain captured launch by launch in turn (A/B in DESIGN.md)
         self.interleave_pano = os.environ.get('DSRG_INTERLEAVE_PANO', '1') == '1'
+        self.pano_split = int(os.environ.get('DSRG_PANO_SPLIT', '2'))
         self.split_big = int(os.environ.get('DSRG_SPLIT_BIG', '2'))      # the longer branch as up to this many part-batch chains (_x_layers_two_streams; 1 = whole;
-                                                                         # 3 or 4, i.e. four or five concurrent chains, is 15-25 % SLOWER than 2)
+                                                                         # 3 or 4 parts measure the same as 2 with HIP's default of 4 hardware queues)
         self.split_ratio = float(os.environ.get('DSRG_SPLIT_RATIO', '1.75'))
         self._fold = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
@@ -636,14 +637,20 @@ class GlocalTextPathNavCMT(nn.Module):
                 obj_rows, O = yield from self._objv2_tokens_gen(W, obj_img_fts, obj_lens, nav_types)
                 K.group_mean(obj_rows, O, out=cat[..., H:])
 
-            def view_chain():
-                img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
+            def view_chain(b0, b1):
+                img = Fn.linear_ln(view_img_fts[b0:b1].to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
                 yield
-                x = self._pano_tokens(W, img, loc_fts, nav_types)
+                x = self._pano_tokens(W, img, loc_fts[b0:b1], nav_types[b0:b1])
                 yield
-                x = yield from self._pano_encoder_gen(W, x, km)
-                Fn.layernorm(x, g, b, 1e-12, out=cat[..., :H])
-            self._run_interleaved(obj_chain(), view_chain())
+                kmp = km if (b0, b1) == (0, B) else (K.KeyLens(km.lens[b0:b1], km.seg) if isinstance(km, K.KeyLens) else km[b0:b1])
+                x = yield from self._pano_encoder_gen(W, x, kmp)
+                Fn.layernorm(x, g, b, 1e-12, out=cat[b0:b1, :, :H])
+            # the view chain is the longer one (~250 vs ~190 us of kernels at B = 64): as two half-batch chains beside the
+            # object chain (three chains, as in the navigation call; pano_split = 1: whole)
+            if self.pano_split > 1 and B % 2 == 0 and B >= 16:
+                self._run_interleaved(view_chain(0, B // 2), obj_chain(), view_chain(B // 2, B))
+            else:
+                self._run_interleaved(obj_chain(), view_chain(0, B))
         else:
             objs = self._fork(lambda: self._objv2_tokens(W, obj_img_fts, obj_lens, nav_types))
             img = Fn.linear_ln(view_img_fts.to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
@@ -909,14 +916,13 @@ class GlocalTextPathNavCMT(nn.Module):
         episode - R2R's 38 viewpoint tokens against 20 graph nodes, REVERIE's 58 against 20, 100 graph nodes against 38 - the
         larger one runs as two chains over the halves of the episode batch (episodes are independent in every launch), so
         that three chains of comparable length share the chip to the end instead of the long one running alone, on a
-        two-thirds-empty chip, once the short one is through (same box: c3 1.380 -> 1.319 ms, c2 0.996 -> 0.991;
-        four parts: 1.26)."""
+        two-thirds-empty chip, once the short one is through (same box: c3 1.380 -> 1.319 ms, c5 1.741 -> 1.648, c2 0.996 -> 0.991)."""
         fa = final_aux or [None, None]
         B, G, Vp = g.shape[0], g.shape[1], v.shape[1]
         big = 'l' if Vp >= G else 'g'
-        # number of chains of the longer branch: its rows over the shorter one's, rounded, at most split_big (2: with a third
-        # or fourth part - four or five concurrent chains - the step is 15-25 % slower: c3 1.33 -> 1.58 ms, c5 1.70 -> 1.92)
-        # and at least 8 episodes per chain
+        # number of chains of the longer branch: its rows over the shorter one's, rounded, at most split_big (2: a third or
+        # fourth part buys nothing - c3 1.314 vs 1.326 ms, c5 1.643 vs 1.665 - and, with GPU_MAX_HW_QUEUES off its default of
+        # 4, four or more concurrent chains cost 15-110 %) and at least 8 episodes per chain
         ns = min(self.split_big, int(max(G, Vp) / min(G, Vp) + 0.5), B // 8)
         if ns > 1 and self._fuse_ok(self.config.hidden_size) and max(G, Vp) >= self.split_ratio * min(G, Vp):
             cut = [(i * B + ns // 2) // ns for i in range(ns + 1)]          # episode ranges, sizes differing by at most one

@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/dsrg_amd/csrc; out=$src/variants; mkdir -p $out/obj_$name
-for f in gemm rowops attention train train_rows graphmap; do
+for f in gemm rowops attention train train_rows graphmap optim; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$root/include "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
 done
 wait
