@@ -896,7 +896,14 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
     const char* e = nullptr;
     const bool big = !fuse && maxM > 64 && minK >= 512 && count_tiles(a, 128, 128) >= 1000;      // the 8-wave 256x128 tile below
     if (big) e = nullptr;
-    else if (!only64 && !fuse_rs && maxM > 64 && minN >= 2304 && maxK <= 1024) e = (wide_env && !fuse) ? wide_env : (bf16 ? "128x128x2:200" : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
+    else if (!only64 && !fuse_rs && maxM > 64 && minN >= 2304 && maxK <= 1024) {
+      // (DSRG_GEMM_WIDE_MIN: the tile count from which the default wide tile applies, LayerNorm-fused launches included)
+      static const char* wmin_env = getenv("DSRG_GEMM_WIDE_MIN");
+      static char wide_def[32];
+      static const bool wide_def_init = (snprintf(wide_def, sizeof(wide_def), "128x128x2:%d", wmin_env ? atoi(wmin_env) : 200), true);
+      (void)wide_def_init;
+      e = (wide_env && !fuse) ? wide_env : (bf16 ? wide_def : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
+    }
     else if (!only64 && !fuse_a && maxM > 64 && minK >= 2048) e = (longk_env && !fuse) ? longk_env : (bf16 || !fuse ? "128x64x4:1" : nullptr);    // FFN-out: 1.136 -> 1.128 ms per c2 step
     else if (!fuse && maxM > 64 && maxK <= 1024) { static const char* narrow_env = getenv("DSRG_GEMM_NARROW"); e = narrow_env; }
     while (e && *e) {
