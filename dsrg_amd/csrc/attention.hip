@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// Short-key variant of the bf16 MFMA attention (every problem of the launch has Nk <= 128, no dropout): the nav-step's
+// Short-key variant of the bf16 MFMA attention (every problem of the launch has Nk <= 128): the nav-step's
 // launches are 768 workgroups that each live for one dependent chain  global load -> LDS write -> barrier -> LDS read ->
 // S -> softmax -> P.V -> store  (in-kernel stamps, profiles/r03s_attn_stamps_before.txt: 5.8 k cycles of staging + 3.9 k of
 // compute per workgroup for ~30 MFMAs).  Here the chain is shorter:
@@ -450,10 +450,11 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
 // NTL = number of 16-key tiles (2, 4, 6, 8) of the LONGEST problem of the launch, a template parameter so that a launch
 // of 20-key problems carries 16 K-fragment registers, not 64.  Same arithmetic, in the same order, as attention_mfma_kernel.
 constexpr int VDS = 160;
-template <int NTL, bool SPREL>
+template <int NTL, bool SPREL, bool DROP = false>
 __global__ __launch_bounds__(256, NTL <= 6 ? 3 : 2) void attention_mfma_direct_kernel(const AttnGroup grp) {
   ATTN_STAMP(0);
   ATTN_PICK_PROBLEM(grp)
+  if constexpr (DROP) { if (a.seed_off) a.seed += *a.seed_off; }
   constexpr int NP = NTL / 2;                                   // 32-row passes of the V stage
   __shared__ __attribute__((aligned(16))) char Vs[NTL * 16 * VDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -578,6 +579,17 @@ __global__ __launch_bounds__(256, NTL <= 6 ? 3 : 2) void attention_mfma_direct_k
         psum += p;
       }
     l_run = psum;
+    if (DROP && qrow < a.Nq) {                                  // the normaliser keeps the undropped sum; only P.V sees the mask
+      const float ik = 1.0f / (1.0f - a.p_drop);
+      const size_t rbase = (((size_t)b * a.NH + h) * a.Nq + qrow) * nk;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kl = t * 16 + 4 * g + r;
+          if (kl < nk) s[t][r] *= drop_keep(a.seed, rbase + kl, a.p_drop, ik);
+        }
+    }
   }
   __syncthreads();                                              // V staged (every wave, active or not, wrote its rows)
   if (!active) return;
@@ -1263,12 +1275,14 @@ extern "C" int dsrg_attention_fwd_grouped(const dsrg_attn_problem_t* problems, i
   static const int direct_mode = []() { const char* e = getenv("DSRG_ATTN_DIRECT"); return e ? atoi(e) : 1; }();
   bool k_near = true;
   for (int i = 0; i < grp.n; ++i) k_near = k_near && grp.a[i].k_rs <= 4 * NH * 64;
-  if (mfma_ok && !drop && max_nk <= KC && (direct_mode == 2 || (direct_mode == 1 && k_near))) {
+  if (mfma_ok && max_nk <= KC && (direct_mode == 2 || (direct_mode == 1 && k_near))) {
     const int ntl = ((max_nk + 31) / 32) * 2;
-#define DSRG_ATTN_DIRECT_LAUNCH(NTL_)                                                                         \
-    do {                                                                                                      \
-      if (any_dists) hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, true>), grid, block, 0, st, grp);  \
-      else hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, false>), grid, block, 0, st, grp);           \
+#define DSRG_ATTN_DIRECT_LAUNCH(NTL_)                                                                                       \
+    do {                                                                                                                    \
+      if (any_dists && drop) hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, true, true>), grid, block, 0, st, grp);   \
+      else if (any_dists) hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, true, false>), grid, block, 0, st, grp);     \
+      else if (drop) hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, false, true>), grid, block, 0, st, grp);          \
+      else hipLaunchKernelGGL((attention_mfma_direct_kernel<NTL_, false, false>), grid, block, 0, st, grp);                   \
     } while (0)
     if (ntl == 2) DSRG_ATTN_DIRECT_LAUNCH(2);
     else if (ntl == 4) DSRG_ATTN_DIRECT_LAUNCH(4);
