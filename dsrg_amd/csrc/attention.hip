@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, NTL <= 6 ? 3 : 2) void attention_mfma_direct_k
     if (use_sp) {
       sw = a.sprel_w[0]; sb = a.sprel_b[0];
       const float* dr = a.dists + ((size_t)b * a.Nq + qr) * nk;
-      const bool al = (nk & 3) == 0;                             // rows of pair distances are 16-byte aligned
+      const bool al = (nk & 3) == 0 && ((uintptr_t)a.dists & 15) == 0;      // rows of pair distances are 16-byte aligned
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         const int k4 = t * 16 + 4 * g;
