@@ -11,7 +11,7 @@ ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 MASK_NONE, MASK_NEG10000, MASK_NEGINF, MASK_PLUS1 = 0, 1, 2, 3
 IDX_I32, IDX_I64, IDX_F32 = 0, 1, 2
 MAX_GROUPS = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class HeadTailProblem(C.Structure):
@@ -109,6 +109,8 @@ SIGNATURES = {
     'dsrg_embed_ln_fwd': (C.c_int, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
                                     _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_embed_ln_fwd_seg': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
+                                        _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
+    'dsrg_embed_ln_fwd_lnb': (C.c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I,
                                         _P, _P, _P, _F, _P, _I, _I, _I, _I, _P]),
     'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

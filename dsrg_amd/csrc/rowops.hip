@@ -184,6 +184,8 @@ struct EmbedArgs {
   float eps; void* out; int ldo; int M; int H;
   // base row gathered from two tables by per-episode lengths (dsrg_embed_ln_fwd_seg); seg_T = 0: base row = row
   const void* base2; int ldb2; int seg_T, seg_V, seg_No; const int64_t* lens0; const int64_t* lens1;
+  // optional LayerNorm on the base row before it is added (dsrg_embed_ln_fwd_lnb; rows without a base stay zero)
+  const float* lnb_g; const float* lnb_b;
 };
 
 __device__ __forceinline__ int embed_index(const EmbedIdx& ix, int row) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * EWAVES) void embed_ln_kernel(const EmbedArgs a
   asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
                "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
                "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
-  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1));
+  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1), "s"(a.lnb_g), "s"(a.lnb_b));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H, HS = H + 4;
   const int row = blockIdx.x * EWAVES + wave;
@@ -262,13 +264,17 @@ __global__ __launch_bounds__(64 * EWAVES) void embed_ln_kernel(const EmbedArgs a
   const float fl = a.feat ? a.feat[(size_t)rowc * a.ldf + min(lane, a.F - 1)] : 0.f;
   const int i1 = a.E1 ? embed_index(a.i1, rowc) : 0, i2 = a.E2 ? embed_index(a.i2, rowc) : 0;
   typename Raw4<T>::type rb[NV];
-  float4 l1[NV], l2[NV], lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV];
+  float4 l1[NV], l2[NV], lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV], g0[NV], b0[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) l1[i] = l2[i] = lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = z4;
+  for (int i = 0; i < NV; ++i) l1[i] = l2[i] = lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = g0[i] = b0[i] = z4;
   // (every condition below is uniform: a scalar branch around a batch of loads, nothing waits inside it)
   if (brow) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) rb[i] = raw_ld4(brow + cc[i]);
+  }
+  if (a.lnb_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g0[i] = *reinterpret_cast<const float4*>(a.lnb_g + cc[i]); b0[i] = *reinterpret_cast<const float4*>(a.lnb_b + cc[i]); }
   }
   if (a.E1) {
 #pragma unroll
@@ -333,11 +339,12 @@ __global__ __launch_bounds__(64 * EWAVES) void embed_ln_kernel(const EmbedArgs a
     if (a.lnf_g) ln_row_pre<NV>(v, ok, H, g1, b1, a.eps);
   }
   EMBED_STAMP(4);
+  float4 lb[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const float4 lb = brow ? raw4(rb[i]) : z4;
-    v[i] = f4add(f4add(f4add(lb, l1[i]), f4add(l2[i], lv[i])), v[i]);
-  }
+  for (int i = 0; i < NV; ++i) lb[i] = brow ? raw4(rb[i]) : z4;
+  if (a.lnb_g && brow) ln_row_pre<NV>(lb, ok, H, g0, b0, a.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = f4add(f4add(f4add(lb[i], l1[i]), f4add(l2[i], lv[i])), v[i]);
   if (a.lno_g) ln_row_pre<NV>(v, ok, H, g2, b2, a.eps);
   EMBED_STAMP(5);
   T* out = reinterpret_cast<T*>(a.out);
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void embed_ln_regw_kernel(const EmbedArgs a) {
   asm volatile("" ::"s"(a.base), "s"(a.ldb), "s"(a.feat), "s"(a.ldf), "s"(a.F), "s"(a.Wf), "s"(a.bf), "s"(a.lnf_g), "s"(a.lnf_b), "s"(a.E1),
                "s"(a.i1.p), "s"(a.i1.kind), "s"(a.i1.stride), "s"(a.i1.div), "s"(a.E2), "s"(a.i2.p), "s"(a.i2.kind), "s"(a.i2.stride),
                "s"(a.i2.div), "s"(a.vec), "s"(a.lno_g), "s"(a.lno_b), "s"(a.eps), "s"(a.out), "s"(a.ldo), "s"(a.M), "s"(a.H));
-  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1));
+  asm volatile("" ::"s"(a.base2), "s"(a.ldb2), "s"(a.seg_T), "s"(a.seg_V), "s"(a.seg_No), "s"(a.lens0), "s"(a.lens1), "s"(a.lnb_g), "s"(a.lnb_b));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = a.H;
   const int row0 = (blockIdx.x * 4 + wave) * ER;
@@ -397,9 +404,13 @@ __global__ __launch_bounds__(256) void embed_ln_regw_kernel(const EmbedArgs a) {
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int k = 0; k < F; ++k) w[i][k] = W4[(size_t)(cc[i] >> 2) * F + k];
-  float4 lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV];
+  float4 lv[NV], bfv[NV], g1[NV], b1[NV], g2[NV], b2[NV], g0[NV], b0[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = z4;
+  for (int i = 0; i < NV; ++i) lv[i] = bfv[i] = g1[i] = b1[i] = g2[i] = b2[i] = g0[i] = b0[i] = z4;
+  if (a.lnb_g) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { g0[i] = *reinterpret_cast<const float4*>(a.lnb_g + cc[i]); b0[i] = *reinterpret_cast<const float4*>(a.lnb_b + cc[i]); }
+  }
   if (a.vec) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) lv[i] = *reinterpret_cast<const float4*>(a.vec + cc[i]);
@@ -455,11 +466,12 @@ __global__ __launch_bounds__(256) void embed_ln_regw_kernel(const EmbedArgs a) {
       v[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (a.lnf_g) ln_row_pre<NV>(v, ok, H, g1, b1, a.eps);
+    float4 lb[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const float4 lb = brow[r] ? raw4(rb[r][i]) : z4;
-      v[i] = f4add(f4add(f4add(lb, l1[r][i]), f4add(l2[r][i], lv[i])), v[i]);
-    }
+    for (int i = 0; i < NV; ++i) lb[i] = brow[r] ? raw4(rb[r][i]) : z4;
+    if (a.lnb_g && brow[r]) ln_row_pre<NV>(lb, ok, H, g0, b0, a.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f4add(f4add(f4add(lb[i], l1[r][i]), f4add(l2[r][i], lv[i])), v[i]);
     if (a.lno_g) ln_row_pre<NV>(v, ok, H, g2, b2, a.eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -953,14 +965,16 @@ extern "C" int dsrg_embed_ln_fwd(const void* base, int ldb, const float* feat, i
                                dtype, stream);
 }
 
-extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
-                                     const int64_t* lens0, const int64_t* lens1,
-                                     const float* feat, int ldf, int F, const float* Wf, const float* bf,
-                                     const float* lnf_gamma, const float* lnf_beta,
-                                     const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
-                                     const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
-                                     const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
-                                     void* out, int ldo, int M, int H, int dtype, void* stream) {
+static int embed_ln_impl(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
+                         const int64_t* lens0, const int64_t* lens1,
+                         const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                         const float* lnf_gamma, const float* lnf_beta,
+                         const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                         const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                         const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                         void* out, int ldo, int M, int H, int dtype, void* stream, const float* lnb_gamma, const float* lnb_beta) {
+  DSRG_CHECK((!lnb_gamma && !lnb_beta) || (lnb_gamma && lnb_beta && base && al16(lnb_gamma) && al16(lnb_beta)),
+             "dsrg_embed_ln_fwd_lnb: the base LayerNorm needs a base, gamma and beta (16-byte aligned)");
   DSRG_CHECK(seg_T >= 0 && (seg_T == 0 || (base && base2 && lens0 && lens1 && seg_V >= 1 && seg_No >= 1 && M % seg_T == 0 && ldb2 % 4 == 0 &&
                                            ldb2 >= H && ((uintptr_t)base2 & 7) == 0)),
              "dsrg_embed_ln_fwd_seg: the gathered base needs both tables, both length vectors, M %% seg_T == 0 and an aligned base2");
@@ -979,7 +993,7 @@ extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base
   if (M == 0) return DSRG_OK;
   EmbedArgs a{base, ldb, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, {idx1, idx1_kind, idx1_stride, idx1_div},
               E2, {idx2, idx2_kind, idx2_stride, idx2_div}, vec, lno_gamma, lno_beta, eps, out, ldo, M, H,
-              base2, ldb2, seg_T, seg_V, seg_No, lens0, lens1};
+              base2, ldb2, seg_T, seg_V, seg_No, lens0, lens1, lnb_gamma, lnb_beta};
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + EWAVES - 1) / EWAVES), block(64 * EWAVES);
   const size_t lds = feat ? (size_t)F * (H + 4) * sizeof(float) : 0;     // <= 16 * 1028 * 4 = 65,792 B
@@ -1016,6 +1030,31 @@ extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base
 #undef DSRG_EMBED_LAUNCH
   DSRG_LAUNCH_CHECK("dsrg_embed_ln_fwd");
   return DSRG_OK;
+}
+
+extern "C" int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
+                                     const int64_t* lens0, const int64_t* lens1,
+                                     const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                                     const float* lnf_gamma, const float* lnf_beta,
+                                     const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                                     const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                                     const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                                     void* out, int ldo, int M, int H, int dtype, void* stream) {
+  return embed_ln_impl(base, ldb, base2, ldb2, seg_T, seg_V, seg_No, lens0, lens1, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, idx1, idx1_kind,
+                       idx1_stride, idx1_div, E2, idx2, idx2_kind, idx2_stride, idx2_div, vec, lno_gamma, lno_beta, eps, out, ldo, M, H, dtype,
+                       stream, nullptr, nullptr);
+}
+
+extern "C" int dsrg_embed_ln_fwd_lnb(const void* base, int ldb, const float* lnb_gamma, const float* lnb_beta,
+                                     const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                                     const float* lnf_gamma, const float* lnf_beta,
+                                     const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                                     const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                                     const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                                     void* out, int ldo, int M, int H, int dtype, void* stream) {
+  return embed_ln_impl(base, ldb, nullptr, 0, 0, 0, 0, nullptr, nullptr, feat, ldf, F, Wf, bf, lnf_gamma, lnf_beta, E1, idx1, idx1_kind,
+                       idx1_stride, idx1_div, E2, idx2, idx2_kind, idx2_stride, idx2_div, vec, lno_gamma, lno_beta, eps, out, ldo, M, H, dtype,
+                       stream, lnb_gamma, lnb_beta);
 }
 
 extern "C" int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, int M, int G, int H, int dtype, void* stream) {

@@ -1053,19 +1053,20 @@ class _EmbedLnFn(torch.autograd.Function):
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
-             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, E1_padding_idx=None, seg=None):
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, E1_padding_idx=None, seg=None, lnb=None):
     """Token-embedding sum + LayerNorm(s) (BertEmbeddings and the four visual token sites, see include/dsrg_hip.h).
-    E1_padding_idx: row of E1 that receives no gradient (the word table is nn.Embedding(padding_idx=0) in the reference)."""
+    E1_padding_idx: row of E1 that receives no gradient (the word table is nn.Embedding(padding_idx=0) in the reference).
+    lnb = (gamma, beta): LayerNorm on the base row before it is added (inference path, as seg)."""
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
     ts = (base, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
     if _needs_grad(ts):
-        if seg is not None:
-            raise _lib.DsrgHipError('embed_ln: the gathered base (seg) is an inference-path feature')
+        if seg is not None or lnb is not None:
+            raise _lib.DsrgHipError('embed_ln: the gathered base (seg) and the base LayerNorm (lnb) are inference-path features')
         if base is not None and base.dim() != 2:
             base = base.reshape(M, H)
         return _EmbedLnFn.apply((M, H, dtype, device, idx1, idx2, eps, E1_padding_idx), base, feat, Wf, bf, lnf_g, lnf_b, E1, E2, vec, lno_g, lno_b)
-    return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out, seg)
+    return K.embed_ln(M, H, dtype, device, base, feat, Wf, bf, lnf, E1, idx1, E2, idx2, vec, lno, eps, out, seg, lnb)
 
 
 class _GroupMeanFn(torch.autograd.Function):

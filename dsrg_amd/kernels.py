@@ -526,10 +526,10 @@ def _idx(t, M, what):
 
 
 def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=None, E1=None, idx1=None,
-             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, seg=None):
+             E2=None, idx2=None, vec=None, lno=None, eps=1e-12, out=None, seg=None, lnb=None):
     """seg = (base2 [B*No, H], T, V, No, lens0 int64 [B], lens1 int64 [B]): the base row of token t of episode b is gathered
     from base (view rows, V per episode) / base2 (object rows, No per episode) / zero by the two lengths
-    (dsrg_embed_ln_fwd_seg)."""
+    (dsrg_embed_ln_fwd_seg).  lnb = (gamma, beta): LayerNorm on the base row before it is added (dsrg_embed_ln_fwd_lnb)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(M, H, device=device, dtype=dtype)
@@ -546,6 +546,8 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
     lnf_g, lnf_b = lnf if lnf is not None else (None, None)
     lno_g, lno_b = lno if lno is not None else (None, None)
     if seg is not None:
+        if lnb is not None:
+            raise _lib.DsrgHipError('embed_ln: lnb and seg are exclusive')
         base2, T_, V_, No_, l0, l1 = seg
         B_ = M // T_
         if base is None or base2.dtype != out.dtype or _rows(base)[0] != B_ * V_ or _rows(base2)[0] != B_ * No_ or \
@@ -554,6 +556,13 @@ def embed_ln(M, H, dtype, device, base=None, feat=None, Wf=None, bf=None, lnf=No
         _lib.check(lib.dsrg_embed_ln_fwd_seg(_p(base), ldb, _p(base2), _rows(base2)[1], T_, V_, No_, _p(l0), _p(l1), _p(feat), ldf, F_, _p(Wf), _p(bf),
                                              _p(lnf_g), _p(lnf_b), _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),
                                              float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd_seg')
+        return out
+    if lnb is not None:
+        if base is None or any(t.dtype != torch.float32 or t.shape != (H,) or not t.is_contiguous() for t in lnb):
+            raise _lib.DsrgHipError('embed_ln: lnb needs a base and fp32 [H] gamma / beta')
+        _lib.check(lib.dsrg_embed_ln_fwd_lnb(_p(base), ldb, _p(lnb[0]), _p(lnb[1]), _p(feat), ldf, F_, _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b),
+                                             _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),
+                                             float(eps), _p(out), ldo, M, H, _dt(out), _stream()), 'dsrg_embed_ln_fwd_lnb')
         return out
     _lib.check(lib.dsrg_embed_ln_fwd(_p(base), ldb, _p(feat), ldf, F_, _p(Wf), _p(bf), _p(lnf_g), _p(lnf_b),
                                      _p(E1), _p(i1), k1, s1, d1, _p(E2), _p(i2), k2, s2, d2, _p(vec), _p(lno_g), _p(lno_b),

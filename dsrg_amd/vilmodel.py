@@ -189,6 +189,7 @@ class GlocalTextPathNavCMT(nn.Module):
         self.interleave_branches = os.environ.get('DSRG_INTERLEAVE', '0') == '1'
         # panorama call: view chain and object-token chain captured launch by launch in turn (A/B in DESIGN.md)
         self.interleave_pano = os.environ.get('DSRG_INTERLEAVE_PANO', '1') == '1'
+        self.fold_img_ln = os.environ.get('DSRG_FOLD_IMG_LN', '1') == '1'      # panorama: img_layer_norm inside the token-embedding kernel
         self.pano_split = int(os.environ.get('DSRG_PANO_SPLIT', '1'))
         self.split_big = int(os.environ.get('DSRG_SPLIT_BIG', '2'))      # the longer branch as up to this many part-batch chains (_x_layers_two_streams; 1 = whole;
                                                                          # 3 or 4 parts measure the same as 2 with HIP's default of 4 hardware queues)
@@ -506,7 +507,7 @@ class GlocalTextPathNavCMT(nn.Module):
             yield
         return x
 
-    def _pano_tokens(self, W, base, loc_fts, nav_types, seg=None):
+    def _pano_tokens(self, W, base, loc_fts, nav_types, seg=None, lnb=None):
         """seg (inference, REVERIE): (object rows [B*No, H], No, view_lens, obj_lens) - the per-episode token assembly
         [views[:vl] ; objects[:ol] ; zero pad] is done by the embedding kernel's base-row gather (kernels.embed_ln)"""
         cfg = self.config
@@ -516,7 +517,7 @@ class GlocalTextPathNavCMT(nn.Module):
                         feat=loc_fts.float().reshape(B * T, -1).contiguous(), Wf=W['loc.w'], bf=W['loc.b'],
                         lnf=(W['loc.ln.g'], W['loc.ln.b']), E1=W['nav_type'], idx1=nav_types.reshape(-1),
                         vec=W['emb.type'][1], lno=(W['pano.ln.g'], W['pano.ln.b']),
-                        seg=None if seg is None else (seg[0], T, V, seg[1], seg[2], seg[3])).view(B, T, H)
+                        seg=None if seg is None else (seg[0], T, V, seg[1], seg[2], seg[3]), lnb=lnb).view(B, T, H)
         # FT REVERIE: nn.Dropout(config.image_dropout_prob) (vilmodel_reverie.py:588); R2R and both pre-training twins:
         # hidden_dropout_prob (vilmodel.py:576, PT/vilmodel_reverie.py:514)
         ft_reverie = self.REVERIE and not self.PRETRAIN
@@ -638,9 +639,14 @@ class GlocalTextPathNavCMT(nn.Module):
                 K.group_mean(obj_rows, O, out=cat[..., H:])
 
             def view_chain(b0, b1):
-                img = Fn.linear_ln(view_img_fts[b0:b1].to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
-                yield
-                x = self._pano_tokens(W, img, loc_fts[b0:b1], nav_types[b0:b1])
+                if self.fold_img_ln:      # img_layer_norm inside the token kernel (dsrg_embed_ln_fwd_lnb): no LayerNorm launch
+                    img = K.gemm([(view_img_fts[b0:b1].to(cd), W['img.lin.w'], W['img.lin.b'], None)])[0]
+                    yield
+                    x = self._pano_tokens(W, img, loc_fts[b0:b1], nav_types[b0:b1], lnb=(W['img.ln.g'], W['img.ln.b']))
+                else:
+                    img = Fn.linear_ln(view_img_fts[b0:b1].to(cd), W['img.lin.w'], W['img.lin.b'], W['img.ln.g'], W['img.ln.b'], 1e-12)
+                    yield
+                    x = self._pano_tokens(W, img, loc_fts[b0:b1], nav_types[b0:b1])
                 yield
                 kmp = km if (b0, b1) == (0, B) else (K.KeyLens(km.lens[b0:b1], km.seg) if isinstance(km, K.KeyLens) else km[b0:b1])
                 x = yield from self._pano_encoder_gen(W, x, kmp)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSRG_ABI_VERSION 13
+#define DSRG_ABI_VERSION 14
 
 enum { DSRG_F32 = 0, DSRG_BF16 = 1 };
 enum { DSRG_OK = 0, DSRG_EINVAL = -1, DSRG_ELAUNCH = -2, DSRG_EUNSUPPORTED = -3 };
@@ -269,6 +269,19 @@ int dsrg_group_mean_fwd(const void* x, int ldx, void* out, int ldo, int M, int G
  * base2 has leading dim ldb2.  seg_T = 0: plain dsrg_embed_ln_fwd. */
 int dsrg_embed_ln_fwd_seg(const void* base, int ldb, const void* base2, int ldb2, int seg_T, int seg_V, int seg_No,
                           const int64_t* lens0, const int64_t* lens1,
+                          const float* feat, int ldf, int F, const float* Wf, const float* bf,
+                          const float* lnf_gamma, const float* lnf_beta,
+                          const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,
+                          const float* E2, const void* idx2, int idx2_kind, int idx2_stride, int idx2_div,
+                          const float* vec, const float* lno_gamma, const float* lno_beta, float eps,
+                          void* out, int ldo, int M, int H, int dtype, void* stream);
+
+/* dsrg_embed_ln_fwd with a LayerNorm on the BASE row before it is added (same eps):
+ *   out[r,:] = LNo( LNb(base[r,:]) + LNf( Wf.feat[r,:] + bf ) + E1[..] + E2[..] + vec )
+ * The panorama tokens of FT/vilmodel.py:693-695, 719-724 - img_layer_norm(img_linear(view features)) is the base of the token
+ * sum - without a LayerNorm launch between the projection and the token kernel: base is the projection's output as the
+ * GEMM stored it (storage dtype).  lnb_gamma / lnb_beta fp32 [H], 16-byte aligned, both or neither. */
+int dsrg_embed_ln_fwd_lnb(const void* base, int ldb, const float* lnb_gamma, const float* lnb_beta,
                           const float* feat, int ldf, int F, const float* Wf, const float* bf,
                           const float* lnf_gamma, const float* lnf_beta,
                           const float* E1, const void* idx1, int idx1_kind, int idx1_stride, int idx1_div,

@@ -353,6 +353,19 @@ def test_layernorm_and_embed(K, dtype, H):
     ref = base.float() + torch.nn.functional.layer_norm(f14 @ W14.T + bf, (H,), g, b, 1e-12) + E1[i1.long()]
     # no output LayerNorm here: values reach ~8, so the bf16 bound is half an ulp of the largest value
     assert (out.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2.0 ** -8 * ref.abs().max().item())
+    # LayerNorm on the base row inside the kernel (dsrg_embed_ln_fwd_lnb): the register-weight kernel (F = 7, 14) and the
+    # LDS-staged one (F = 5); equal to a LayerNorm launch in front of the plain call (bit for bit in fp32)
+    gb, bb = 1 + 0.1 * _r(H, seed=20), 0.1 * _r(H, seed=21)
+    for Fx, fx, Wx in ((7, feat8[:, :7], Wf), (14, f14, W14), (5, feat8[:, :5].contiguous(), _r(H, 5, seed=22, scale=0.3))):
+        kw = dict(feat=fx, Wf=Wx, bf=bf, lnf=(g, b), E1=E1, idx1=i1, vec=vec, lno=(b + 1, g - 1))
+        got = K.embed_ln(M, H, dtype, 'cuda', base=base, lnb=(gb, bb), **kw)
+        two = K.embed_ln(M, H, dtype, 'cuda', base=K.layernorm(base, gb, bb, 1e-12, None, dtype), **kw)
+        t = torch.nn.functional.layer_norm(fx @ Wx.T + bf, (H,), g, b, 1e-12)
+        ref = torch.nn.functional.layer_norm(torch.nn.functional.layer_norm(base.float(), (H,), gb, bb, 1e-12) + t + E1[i1.long()] + vec,
+                                             (H,), b + 1, g - 1, 1e-12)
+        assert (got.float() - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 3e-2), Fx
+        if dtype == torch.float32:
+            assert torch.equal(got, two), Fx
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
