@@ -115,6 +115,7 @@ SIGNATURES = {
     'dsrg_group_mean_fwd': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_fwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'dsrg_gaa_pool_fwd_ex': (C.c_int, [_P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
+    'dsrg_gaa_pool_fwd_ln': (C.c_int, [_P, _L, _P, _P, _F, _P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     'dsrg_head_tail_fwd': (C.c_int, [_P, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     'dsrg_nav_logits_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'dsrg_nav_logits_fwd_og': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -498,7 +498,9 @@ constexpr int GWAVES = 16, GVPW = 4;      // V <= 64
 template <typename T>
 __global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x, long x_bs, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ out, T* __restrict__ out2, long out2_bs, const int64_t* __restrict__ idx2,
-                                                        int idx2_max, int V, int H) {
+                                                        int idx2_max, int V, int H, const float* __restrict__ ln_g = nullptr,
+                                                        const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f,
+                                                        T* __restrict__ rows_out = nullptr, long rows_bs = 0) {
   __shared__ float sc[64];
   extern __shared__ __attribute__((aligned(16))) float part[];     // [GWAVES][H]
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -524,6 +526,36 @@ __global__ __launch_bounds__(1024) void gaa_pool_kernel(const T* __restrict__ x,
     if (!okc) ww[i] = z4;
 #pragma unroll
     for (int r = 0; r < GVPW; ++r) row[r][i] = (okc && wave + GWAVES * r < V) ? raw4(raw[r][i]) : z4;
+  }
+  // dsrg_gaa_pool_fwd_ln: the rows come un-normalised (the vis_obj_linear GEMM's output as stored); every wave normalises ITS
+  // rows (the whole row is in the wave), stores them to rows_out in the storage dtype and pools the stored values - what a
+  // LayerNorm launch in front of this kernel would have produced, without the launch
+  if (ln_g) {
+    float4 lg[MAXV], lb[MAXV];
+    bool ok[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int cc = min((i * 64 + lane) * 4, H - 4);
+      ok[i] = i < nv && (i * 64 + lane) * 4 < H;
+      lg[i] = *reinterpret_cast<const float4*>(ln_g + cc);
+      lb[i] = *reinterpret_cast<const float4*>(ln_b + cc);
+    }
+#pragma unroll
+    for (int r = 0; r < GVPW; ++r) {
+      const int v = wave + GWAVES * r;
+      if (v < V) {                                             // wave-uniform
+        ln_row_pre<MAXV>(row[r], ok, H, lg, lb, ln_eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+          if (ok[i]) {
+            T* dst = rows_out + (size_t)b * rows_bs + (size_t)v * H + (i * 64 + lane) * 4;
+            st4(dst, row[r][i]);
+            if constexpr (sizeof(T) == 2)                           // pool what was stored (rounded to bf16), as the two-launch path does
+              row[r][i] = make_float4(bf2f(f2bf(row[r][i].x)), bf2f(f2bf(row[r][i].y)), bf2f(f2bf(row[r][i].z)), bf2f(f2bf(row[r][i].w)));
+          } else row[r][i] = z4;
+        }
+      }
+    }
   }
 #pragma unroll
   for (int r = 0; r < GVPW; ++r) {
@@ -1086,9 +1118,29 @@ extern "C" int dsrg_gaa_pool_fwd_ex(const void* x, int64_t x_bs, const float* w,
   hipStream_t s = (hipStream_t)stream;
   DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<float>, 65536);     // 16 x 1024 floats + the score vector is just over the 64 KiB default
   DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<bf16_t>, 65536);
-  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, (long)x_bs, w, bias, (float*)out, (float*)out2, (long)out2_bs, idx2, idx2_max, V, H);
-  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, (long)x_bs, w, bias, (bf16_t*)out, (bf16_t*)out2, (long)out2_bs, idx2, idx2_max, V, H);
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, (long)x_bs, w, bias, (float*)out, (float*)out2, (long)out2_bs, idx2, idx2_max, V, H, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr, 0L);
+  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, (long)x_bs, w, bias, (bf16_t*)out, (bf16_t*)out2, (long)out2_bs, idx2, idx2_max, V, H, (const float*)nullptr, (const float*)nullptr, 0.f, (bf16_t*)nullptr, 0L);
   DSRG_LAUNCH_CHECK("dsrg_gaa_pool_fwd");
+  return DSRG_OK;
+}
+
+extern "C" int dsrg_gaa_pool_fwd_ln(const void* x, int64_t x_bs, const float* ln_gamma, const float* ln_beta, float ln_eps, void* rows_out,
+                                    int64_t rows_bs, const float* w, const float* bias, void* out, void* out2, int64_t out2_bs,
+                                    const int64_t* idx2, int idx2_max, int B, int V, int H, int dtype, void* stream) {
+  DSRG_CHECK(ok_dtype(dtype) && x && w && bias && out && ln_gamma && ln_beta && rows_out, "dsrg_gaa_pool_fwd_ln: bad dtype or null pointer");
+  DSRG_CHECK(V >= 1 && V <= 64 && H > 0 && H % 64 == 0 && H <= 1024, "dsrg_gaa_pool_fwd_ln: need 1 <= V <= 64 (got %d), H %% 64 == 0 and H <= 1024", V);
+  DSRG_CHECK(al16(x) && al16(out) && al16(w) && al16(ln_gamma) && al16(ln_beta) && al16(rows_out), "dsrg_gaa_pool_fwd_ln: misaligned pointer");
+  DSRG_CHECK(x_bs >= (int64_t)V * H && x_bs % 8 == 0 && rows_bs >= (int64_t)V * H && rows_bs % 8 == 0,
+             "dsrg_gaa_pool_fwd_ln: x_bs / rows_bs must cover V rows and keep 16-byte alignment");
+  DSRG_CHECK(!out2 || (idx2 && idx2_max >= 1 && out2_bs >= (int64_t)idx2_max * H && out2_bs % 8 == 0 && al16(out2)),
+             "dsrg_gaa_pool_fwd_ln: out2 needs idx2, idx2_max >= 1 and a batch stride that covers idx2_max rows");
+  if (B <= 0) return DSRG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<float>, 65536);
+  DSRG_SET_MAX_LDS_ONCE(&gaa_pool_kernel<bf16_t>, 65536);
+  if (dtype == DSRG_F32) hipLaunchKernelGGL((gaa_pool_kernel<float>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const float*)x, (long)x_bs, w, bias, (float*)out, (float*)out2, (long)out2_bs, idx2, idx2_max, V, H, ln_gamma, ln_beta, ln_eps, (float*)rows_out, (long)rows_bs);
+  else hipLaunchKernelGGL((gaa_pool_kernel<bf16_t>), dim3(B), dim3(1024), (size_t)GWAVES * H * 4, s, (const bf16_t*)x, (long)x_bs, w, bias, (bf16_t*)out, (bf16_t*)out2, (long)out2_bs, idx2, idx2_max, V, H, ln_gamma, ln_beta, ln_eps, (bf16_t*)rows_out, (long)rows_bs);
+  DSRG_LAUNCH_CHECK("dsrg_gaa_pool_fwd_ln");
   return DSRG_OK;
 }
 

@@ -584,15 +584,35 @@ def group_mean(x, G, out=None):
     return out
 
 
-def gaa_pool(x, w, b, scatter=None):
+def gaa_pool(x, w, b, scatter=None, ln=None, rows_out=None):
     """x [B,V,H] (rows contiguous, batch stride free) -> pooled [B,H].  scatter = (buf [B,G,H], idx int64 [B]): the pooled row
-    of episode b is also stored into buf[b, idx[b]] (dsrg_gaa_pool_fwd_ex)."""
+    of episode b is also stored into buf[b, idx[b]] (dsrg_gaa_pool_fwd_ex).
+    ln = (gamma, beta, eps): x is un-normalised; the kernel normalises every row, stores the rows to rows_out ([B,V,H], rows
+    contiguous, batch stride free; fresh if None) and pools them -> (rows_out, pooled) (dsrg_gaa_pool_fwd_ln)."""
     lib = _lib.load()
     _dev(x)
     B, V, H = x.shape
     if x.stride(2) != 1 or x.stride(1) != H:
         raise _lib.DsrgHipError('gaa_pool: x must be [B,V,H] with contiguous rows')
     out = torch.empty(B, H, device=x.device, dtype=x.dtype)
+    if ln is not None:
+        g_, b_, eps_ = ln
+        if rows_out is None:
+            rows_out = torch.empty(B, V, H, device=x.device, dtype=x.dtype)
+        if rows_out.shape != (B, V, H) or rows_out.dtype != x.dtype or rows_out.stride(2) != 1 or rows_out.stride(1) != H or \
+                any(t.dtype != torch.float32 or t.shape != (H,) or not t.is_contiguous() for t in (g_, b_)):
+            raise _lib.DsrgHipError('gaa_pool: ln needs fp32 [H] gamma / beta and a [B,V,H] rows_out of the input dtype with contiguous rows')
+        buf = idx = None
+        if scatter is not None:
+            buf, idx = scatter
+            if buf.dim() != 3 or buf.shape[0] != B or buf.shape[2] != H or buf.stride(2) != 1 or buf.stride(1) != H or buf.dtype != x.dtype \
+                    or idx.dtype != torch.int64 or idx.shape != (B,) or not idx.is_contiguous():
+                raise _lib.DsrgHipError('gaa_pool: scatter needs a [B,G,H] buffer of the input dtype with contiguous rows and int64 indices [B]')
+        bs = lambda t: t.stride(0) if B > 1 else t.shape[1] * H
+        _lib.check(lib.dsrg_gaa_pool_fwd_ln(_p(x), bs(x), _p(g_), _p(b_), float(eps_), _p(rows_out), bs(rows_out), _p(w), _p(b), _p(out), _p(buf),
+                                            (bs(buf) if buf is not None else 0), _p(idx), (buf.shape[1] if buf is not None else 0), B, V, H,
+                                            _dt(x), _stream()), 'dsrg_gaa_pool_fwd_ln')
+        return rows_out, out
     buf = idx = None
     if scatter is not None:
         buf, idx = scatter

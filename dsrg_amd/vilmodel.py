@@ -190,6 +190,9 @@ class GlocalTextPathNavCMT(nn.Module):
         # panorama call: view chain and object-token chain captured launch by launch in turn (A/B in DESIGN.md)
         self.interleave_pano = os.environ.get('DSRG_INTERLEAVE_PANO', '1') == '1'
         self.fold_img_ln = os.environ.get('DSRG_FOLD_IMG_LN', '1') == '1'      # panorama: img_layer_norm inside the token-embedding kernel
+        # ... and vis_obj_linear's LayerNorm inside the GAA kernel: built, bit-identical, measured SLOWER (c2 1.000 -> 1.010 ms: the
+        # GAA kernel is one workgroup per episode, 64 on 256 CUs, and the LayerNorm lengthens exactly that launch); off
+        self.fold_visobj_ln = os.environ.get('DSRG_FOLD_VISOBJ_LN', '0') == '1'
         self.pano_split = int(os.environ.get('DSRG_PANO_SPLIT', '1'))
         self.split_big = int(os.environ.get('DSRG_SPLIT_BIG', '2'))      # the longer branch as up to this many part-batch chains (_x_layers_two_streams; 1 = whole;
                                                                          # 3 or 4 parts measure the same as 2 with HIP's default of 4 hardware queues)
@@ -666,6 +669,13 @@ class GlocalTextPathNavCMT(nn.Module):
             cat = self._concat2(lambda o: Fn.layernorm(x, g, b, 1e-12, out=o) if o is not None else Fn.layernorm(x, g, b, 1e-12),
                                 lambda o: K.group_mean(obj_rows, O, out=o) if o is not None else Fn.group_mean(obj_rows, O),
                                 B, V, H, d, x.device)
+        if self.fold_visobj_ln and not torch.is_grad_enabled() and H % 64 == 0:
+            # vis_obj_linear's LayerNorm inside the GAA kernel (dsrg_gaa_pool_fwd_ln): it normalises the projection's rows, stores
+            # them as pano_embeds and pools them - no LayerNorm launch, no fp32 projection output
+            z = K.gemm([(cat, W['visobj.lin.w'], W['visobj.lin.b'], None)])[0]
+            pano, fused = K.gaa_pool(z, W['gaa.w'], W['gaa.b'], scatter=gmap_scatter, ln=(W['visobj.ln.g'], W['visobj.ln.b'], 1e-12),
+                                     rows_out=pano_out)
+            return pano, pano_masks, fused
         pano = Fn.linear_ln(cat, W['visobj.lin.w'], W['visobj.lin.b'], W['visobj.ln.g'], W['visobj.ln.b'], 1e-12, out=pano_out)
         fused = Fn.gaa_pool(pano, W['gaa.w'], W['gaa.b'], scatter=gmap_scatter)
         return pano, pano_masks, fused

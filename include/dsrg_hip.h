@@ -303,6 +303,13 @@ int dsrg_gaa_pool_fwd(const void* x, const float* w, const float* bias, void* ou
 int dsrg_gaa_pool_fwd_ex(const void* x, int64_t x_bs, const float* w, const float* bias, void* out, void* out2,
                          int64_t out2_bs, const int64_t* idx2, int idx2_max, int B, int V, int H, int dtype,
                          void* stream);
+/* dsrg_gaa_pool_fwd_ex on rows that are still UN-normalised: x [B,V,H] (batch stride x_bs) is the output of vis_obj_linear's
+ * Linear as the GEMM stored it; the kernel applies that Sequential's LayerNorm (FT/vilmodel.py:731-732; gamma / beta fp32 [H])
+ * to every row, stores the normalised rows - the call's pano_embeds - to rows_out (batch stride rows_bs, storage dtype) and
+ * pools the stored values: the LayerNorm launch between the projection and the pooling is gone.  H % 64 == 0. */
+int dsrg_gaa_pool_fwd_ln(const void* x, int64_t x_bs, const float* ln_gamma, const float* ln_beta, float ln_eps, void* rows_out,
+                         int64_t rows_bs, const float* w, const float* bias, void* out, void* out2, int64_t out2_bs,
+                         const int64_t* idx2, int idx2_max, int B, int V, int H, int dtype, void* stream);
 
 /* ---- ClsPrediction tail: score[r] = LN(h[r,:])·w2 + b2 ---------------------------------------------
  * h = relu(Linear(x)) comes from dsrg_gemm_nt (fp32, DSRG_ACT_RELU).  FT/vilmodel.py:616-628

@@ -378,6 +378,16 @@ def test_pool_mean_head_blend(K, dtype):
     ref = (x.float() * a[..., None]).sum(1)
     tol = 1e-5 if dtype == torch.float32 else 1e-2
     assert (out.float() - ref).abs().max().item() <= tol
+    # the same with the LayerNorm in front of it inside the kernel (dsrg_gaa_pool_fwd_ln): rows and pooled vector equal to a
+    # LayerNorm launch followed by the plain call, bit for bit; rows placed with a batch stride, pooled row scattered
+    lg, lb = 1 + 0.1 * _r(H, seed=30), 0.1 * _r(H, seed=31)
+    buf = torch.zeros(B, V + 2, H, device='cuda', dtype=dtype)
+    gm = torch.zeros(B, 7, H, device='cuda', dtype=dtype)
+    idx = torch.arange(B, device='cuda') % 7
+    rows2, pooled2 = K.gaa_pool(x, w, b, scatter=(gm, idx), ln=(lg, lb, 1e-12), rows_out=buf[:, 2:])
+    xn = K.layernorm(x, lg, lb, 1e-12, None, dtype)
+    assert torch.equal(rows2, xn) and torch.equal(buf[:, 2:], xn) and not buf[:, :2].any()
+    assert torch.equal(pooled2, K.gaa_pool(xn, w, b)) and torch.equal(gm[torch.arange(B), idx], pooled2)
     rows = _r(B * V * 3, 128, dtype=dtype)
     out = K.group_mean(rows, 3)
     assert (out.float() - rows.float().reshape(-1, 3, 128).mean(1)).abs().max().item() <= tol
