@@ -152,6 +152,38 @@ def test_graph_replay_equals_eager_at_full_batch(dtype, L, G):
             assert torch.equal(torch.nan_to_num(a[k].float(), neginf=-1e30), torch.nan_to_num(b[k].float(), neginf=-1e30)), k
 
 
+def test_graph_replay_equals_eager_reverie_three_chains():
+    """REVERIE shapes (58 viewpoint tokens against 20 graph nodes): under capture the local branch runs as two half-batch
+    chains beside the global one (vilmodel._x_layers_two_streams, split_big); the replayed step == eager grouped launches,
+    bit for bit, object-grounding logits included."""
+    from dsrg_amd.config import DSRGConfig
+    from dsrg_amd.runner import GraphedNavStep
+    from dsrg_amd.vilmodel_reverie import GlocalTextPathNavCMT
+    B, L, G, No = 16, 80, 20, 20
+    m = GlocalTextPathNavCMT.from_pretrained(None, config=DSRGConfig(), state_dict=common.synth_sd('reverie_c3'), compute_dtype=torch.bfloat16).cuda().eval()
+    assert m.split_big > 1 and 58 >= m.split_ratio * G
+    lb = common.to_t(synth.language_batch(B, L, 77), 'cuda')
+    pbn = synth.panorama_batch(B, 36, 3, 77, reverie=True, No=No)
+    nb = common.to_t(synth.navigation_batch(B, G, 36 + No + 2, 77, ncand=pbn['ncand'], nav_types=pbn['nav_types'], vp_lens=36 + pbn['obj_lens'] + 2,
+                                            reverie=True), 'cuda')
+    pb = common.to_t(pbn, 'cuda')
+    with torch.no_grad():
+        txt = m('language', lb)
+    runs = []
+    for use_graph in (True, False):
+        r = GraphedNavStep(m, txt, lb['txt_masks'], pb, nb, use_graph=use_graph, reverie=True)
+        r.set_text(txt, lb['txt_masks'])
+        outs = []
+        for _ in range(2):
+            o = r.step()
+            torch.cuda.synchronize()
+            outs.append({k: o[k].clone() for k in ('fused_logits', 'local_logits', 'obj_logits', 'cls_embeds', 'vp_embeds')})
+        runs.append(outs)
+    for a, b in zip(*runs):
+        for k in a:
+            assert torch.equal(torch.nan_to_num(a[k].float(), neginf=-1e30), torch.nan_to_num(b[k].float(), neginf=-1e30)), k
+
+
 def test_bf16_agrees_with_fp32_on_clear_margins_at_full_batch():
     """bf16 product path vs the fp32 parity path at B=64: logits within the stated 6e-2, same action wherever the fp32
     top-2 margin exceeds twice that."""
