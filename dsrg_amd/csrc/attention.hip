@@ -895,8 +895,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 //     register index (4g + r), so per-lane scalars (lse / delta of the lane's query, or the mask term of the lane's key)
 //     apply to all of a lane's accumulators;
 //   * the element-wise result (dS, or P) goes STRAIGHT from those accumulators into the B operand of the next MFMA whose
-//     contraction runs over the register index; the other operand is read from a transposed LDS image with the matching
-//     k-slot permutation (two ds_read_b64 32 bytes apart), as the forward does for P.V.
+//     contraction runs over the register index; the other operand is the transpose of a row-major LDS image, read with the
+//     matching k-slot permutation by two ds_read_b64_tr_b16 sixteen rows apart (tfrag_rm), as the direct forward does for P.V.
 // attention_bwd_mfma_dq : grid (ceil(Nq/64), NH, B), wave <-> 16 queries, keys in chunks of 128:
 //     S^T = K Q^T, dP^T = V dO^T (accumulators: rows = keys, lane = query), dS^T -> B operand of dQ^T += K^T dS^T.
 // attention_bwd_mfma_dkv: grid (ceil(Nk/64), NH, B), wave <-> 16 keys, queries in chunks of 128:
@@ -917,34 +917,23 @@ __device__ __forceinline__ void st_rows(char* S, const RowRegs& L, int nr, int n
     if (row < ntile * 16) *reinterpret_cast<uint4*>(S + kswz(row, c)) = row < nr ? L.r[p] : make_uint4(0, 0, 0, 0);
   }
 }
-// the same rows for the transposed image T[d][row] (VRS-byte rows): thread (row = tid & 127, dc0 = tid >> 7) holds chunks dc0 + 2p
-__device__ __forceinline__ void ld_cols(RowRegs& L, const bf16_t* P, int rs, int r0, int nr, int tid) {
-  const int row = tid & 127, dc0 = tid >> 7;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) L.r[p] = *reinterpret_cast<const uint4*>(P + (size_t)(r0 + min(row, nr - 1)) * rs + (dc0 + 2 * p) * 8);
-}
-__device__ __forceinline__ void st_cols(char* St, const RowRegs& L, int nr, int ntile, int tid) {
-  const int row = tid & 127, dc0 = tid >> 7;
-  if (row < ntile * 16) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int dc = dc0 + 2 * p;
-      const uint4 v = row < nr ? L.r[p] : make_uint4(0, 0, 0, 0);
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(St + (dc * 8 + j) * VRS + row * 2) = e[j];
-    }
-  }
-}
 __device__ __forceinline__ float dot8(const uint4& x, const uint4& y) {
   const float4 a0 = raw4(make_uint2(x.x, x.y)), a1 = raw4(make_uint2(x.z, x.w)), b0 = raw4(make_uint2(y.x, y.y)), b1 = raw4(make_uint2(y.z, y.w));
   return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
 }
-// fragment of a transposed image for the MFMA whose B operand comes from a pair (2j, 2j+1) of score tiles
-__device__ __forceinline__ bf16x8 tfrag(const char* St, int dt, int c16, int j, int g) {
-  const char* vp = St + (dt * 16 + c16) * VRS + (32 * j + 4 * g) * 2;
-  const uint2 v0 = *reinterpret_cast<const uint2*>(vp), v1 = *reinterpret_cast<const uint2*>(vp + 32);
-  return __builtin_bit_cast(bf16x8, make_uint4(v0.x, v0.y, v1.x, v1.y));
+// Fragment of the TRANSPOSE of a row-major image (st_rows: 128-byte rows, kswz swizzle) for the MFMA whose B operand comes from a
+// pair (2j, 2j+1) of score tiles, through the gfx950 transposing read ds_read_b64_tr_b16: the 16 lanes of group g supply rows 32j + 4g .. +3 (lane: row c16 >> 2, columns 4 (c16 & 3) .. +3 of the
+// d-tile) and each receives ITS column d = 16 dt + c16 of those four rows; the second read is the same rows 16 further on
+// ((row + 16) has the same swizzle).  Round 3: replaces the transposed images (a second set of global loads and 32 two-byte LDS
+// writes per thread and image) in both backward kernels, as attention_mfma_direct_kernel does for V in the forward.
+__device__ __forceinline__ bf16x8 tfrag_rm(const char* S, int dt, int c16, int j, int g) {
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  const int row = 32 * j + 4 * g + (c16 >> 2), col = dt * 16 + 4 * (c16 & 3);
+  const char* p = S + kswz(row, col >> 3) + ((col & 7) << 1);
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 16 * 128));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
 }
 
 template <bool DROP>
@@ -953,7 +942,6 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
   if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
   __shared__ __attribute__((aligned(16))) char Vs[KC * 128];
-  __shared__ __attribute__((aligned(16))) char Kt[DH * VRS];
   __shared__ float mt[KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -993,16 +981,14 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
     const int nk = min(KC, a.Nk - k0);
     const int ntile = ((nk + 31) / 32) * 2;
     {
-      RowRegs kr, vr, kc;
+      RowRegs kr, vr;
       ld_rows(kr, Kp, a.k_rs, k0, nk, tid);
       ld_rows(vr, Vp, a.v_rs, k0, nk, tid);
-      ld_cols(kc, Kp, a.k_rs, k0, nk, tid);
       uint8_t mkb = 1;
       if (a.kmask) mkb = a.kmask[(size_t)b * a.Nk + k0 + min(tid & (KC - 1), nk - 1)];
       if (k0) __syncthreads();                                 // every wave is done with the previous chunk
       st_rows(Ks, kr, nk, ntile, tid);
       st_rows(Vs, vr, nk, ntile, tid);
-      st_cols(Kt, kc, nk, ntile, tid);
       if (tid < KC) {
         float t = -INFINITY;
         if (tid < nk) {
@@ -1058,7 +1044,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Kt, dt, c16, j, g), pf, dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag_rm(Ks, dt, c16, j, g), pf, dq[dt], 0, 0, 0);
       }
     };
     switch (ntile) {
@@ -1086,8 +1072,6 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
   if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
   __shared__ __attribute__((aligned(16))) char Qs[KC * 128];
   __shared__ __attribute__((aligned(16))) char Gs[KC * 128];
-  __shared__ __attribute__((aligned(16))) char Qt[DH * VRS];
-  __shared__ __attribute__((aligned(16))) char Gt[DH * VRS];
   __shared__ __attribute__((aligned(16))) float Ls[KC];
   __shared__ __attribute__((aligned(16))) float Dl[KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1128,18 +1112,14 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
     const int nq = min(KC, a.Nq - q0);
     const int ntile = ((nq + 31) / 32) * 2;
     {
-      RowRegs qr, gr, qcol, gcol;
+      RowRegs qr, gr;
       ld_rows(qr, Qp, a.q_rs, q0, nq, tid);
       ld_rows(gr, Gp, ba.do_rs, q0, nq, tid);
-      ld_cols(qcol, Qp, a.q_rs, q0, nq, tid);
-      ld_cols(gcol, Gp, ba.do_rs, q0, nq, tid);
       const size_t li = ((size_t)b * a.NH + h) * a.Nq + q0 + min(tid & (KC - 1), nq - 1);
       const float lv = a.lse[li], dl = ba.delta[li];
       if (q0) __syncthreads();                                 // every wave is done with the previous chunk
       st_rows(Qs, qr, nq, ntile, tid);
       st_rows(Gs, gr, nq, ntile, tid);
-      st_cols(Qt, qcol, nq, ntile, tid);
-      st_cols(Gt, gcol, nq, ntile, tid);
       if (tid < KC) {
         Ls[tid] = tid < nq ? lv : INFINITY;                    // exp(s - inf) = 0 for the padding rows
         Dl[tid] = tid < nq ? dl : 0.f;
@@ -1189,8 +1169,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Gt, dt, c16, j, g), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag(Qt, dt, c16, j, g), df, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag_rm(Gs, dt, c16, j, g), pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag_rm(Qs, dt, c16, j, g), df, dk[dt], 0, 0, 0);
         }
       }
     };
