@@ -170,18 +170,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnGroup grp) {
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA attention.  One workgroup per (episode, head, 64-query group); wave w owns the 16-query
 // tile w.  Keys are processed in chunks of 128 with an online softmax, K staged row-major (128-B rows,
-// same XOR swizzle as the GEMM), V staged TRANSPOSED (Vt[d][key], 272-B rows: conflict-free ds_read_b64).
+// same XOR swizzle as the GEMM), V staged the same way and read back TRANSPOSED by ds_read_b64_tr_b16 (tfrag_rm).
 //   S^T tile  = K · Q^T   (v_mfma_f32_16x16x32_bf16, A = K rows, B = Q rows): lane (c = lane&15, g = lane>>4)
 //               holds S[query c][key 16t + 4g + r], r = 0..3  -> the softmax max/sum over keys is in-lane
 //               plus two xor-shuffles (16, 32).
 //   O^T      += V^T · P^T with P taken STRAIGHT from those accumulators as the B operand: k-slot 8g+e of the
 //               MFMA is key 16*t0+4g+e (e<4) / 16*t1+4g+e-4 (e>=4) of a tile pair (t0,t1); the V^T fragment
-//               is read with the same key permutation (two ds_read_b64 32 bytes apart).  No P round trip.
+//               is read with the same key permutation (two transposing reads 16 keys apart).  No P round trip.
 //   lane ends with O[query c][d = 16*dt + 4g + 0..3]  -> 8-byte stores.
-constexpr int KC = 128, NKT = KC / 16, VRS = 272;
+constexpr int KC = 128, NKT = KC / 16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Fragment of the TRANSPOSE of a row-major image (st_rows: 128-byte rows, kswz swizzle) for the MFMA whose B operand comes from a
+// pair (2j, 2j+1) of score tiles, through the gfx950 transposing read ds_read_b64_tr_b16: the 16 lanes of group g supply rows 32j + 4g .. +3 (lane: row c16 >> 2, columns 4 (c16 & 3) .. +3 of the
+// d-tile) and each receives ITS column d = 16 dt + c16 of those four rows; the second read is the same rows 16 further on
+// ((row + 16) has the same swizzle).  Round 3: replaces the transposed images (32 two-byte LDS writes per thread and image,
+// and in the backward kernels a second set of global loads) in the tiled forward and both backward kernels.
+__device__ __forceinline__ bf16x8 tfrag_rm(const char* S, int dt, int c16, int j, int g) {
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  const int row = 32 * j + 4 * g + (c16 >> 2), col = dt * 16 + 4 * (c16 & 3);
+  const char* p = S + kswz(row, col >> 3) + ((col & 7) << 1);
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 16 * 128));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
+}
 
 #ifdef DSRG_ATTN_STAMPS   // diagnostic build only (tools/attn_stamps.py)
 __device__ unsigned long long g_attn_stamps[16384 * 4];
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
   ATTN_PICK_PROBLEM(grp)
   if constexpr (DROP) { if (a.seed_off) a.seed += *a.seed_off; }
   __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
-  __shared__ __attribute__((aligned(16))) char Vt[DH * VRS];
+  __shared__ __attribute__((aligned(16))) char Vs[KC * 128];
   __shared__ float mt[KC];
   __shared__ __attribute__((aligned(16))) float sp[SPREL ? 64 * SPS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -236,20 +251,19 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
   auto chunk = [&](const int k0) {
     const int nk = min(KC, a.Nk - k0);
     const int ntile = ((nk + 31) / 32) * 2;                    // even number of 16-key tiles
-    // ---- stage K (row-major, swizzled) and V (transposed); rows >= nk are zero.  All nine global loads of a thread
+    // ---- stage K and V (both row-major, swizzled; V is read back transposed by tfrag_rm); rows >= nk are zero.  All nine global loads of a thread
     // are issued UNCONDITIONALLY (row index clamped) before the first LDS write: behind per-row conditions the compiler
     // waited for each load before issuing the next - nine memory latencies in a row, 9 k of a workgroup's 17 k cycles
     // (in-kernel stamps, tools/attn_stamps.py).
     {
       const int r = tid >> 3, c = tid & 7;
-      const int key = tid & 127, dc0 = tid >> 7;
       uint4 kreg[4], vreg[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p)
         kreg[p] = *reinterpret_cast<const uint4*>(Kp + (size_t)(k0 + min(r + 32 * p, nk - 1)) * a.k_rs + c * 8);
 #pragma unroll
       for (int p = 0; p < 4; ++p)
-        vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + min(key, nk - 1)) * a.v_rs + (dc0 + 2 * p) * 8);
+        vreg[p] = *reinterpret_cast<const uint4*>(Vp + (size_t)(k0 + min(r + 32 * p, nk - 1)) * a.v_rs + c * 8);
       uint8_t mkb = 1;
       if (a.kmask || a.klens) mkb = key_valid(a, b, k0 + min(tid & (KC - 1), nk - 1)) ? 1 : 0;
       float dreg[SPREL ? 32 : 1];
@@ -273,8 +287,10 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = r + 32 * p;
-        if (row < ntile * 16)
+        if (row < ntile * 16) {
           *reinterpret_cast<uint4*>(Ks + kswz(row, c)) = row < nk ? kreg[p] : make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(Vs + kswz(row, c)) = row < nk ? vreg[p] : make_uint4(0, 0, 0, 0);
+        }
       }
       if constexpr (SPREL) {
         if (use_sp) {
@@ -285,16 +301,6 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
               if (sp_hi) sp[(wave * 16 + i) * SPS + 64 + lane] = dreg[2 * i + 1] * sw + sb;
             }
           }
-        }
-      }
-      if (key < ntile * 16) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int dc = dc0 + 2 * p;
-          const uint4 v = key < nk ? vreg[p] : make_uint4(0, 0, 0, 0);
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(Vt + (dc * 8 + j) * VRS + key * 2) = e[j];
         }
       }
       if (tid < KC) {
@@ -398,12 +404,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * j][r]; pf[4 + r] = (__bf16)s[2 * j + 1][r]; }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const char* vp = Vt + (dt * 16 + c16) * VRS + (32 * j + 4 * g) * 2;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(vp), v1 = *reinterpret_cast<const uint2*>(vp + 32);
-          const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tfrag_rm(Vs, dt, c16, j, g), pf, o[dt], 0, 0, 0);
       }
     }
     };
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, (DROP || SPREL) ? 2 : ATTN_MFMA_MIN_WAVES) voi
   };
   chunk(0);
   for (int k0 = KC; k0 < a.Nk; k0 += KC) {
-    __syncthreads();                                           // every wave is done with the previous chunk's K / V^T
+    __syncthreads();                                           // every wave is done with the previous chunk's K / V
     chunk(k0);
   }
   ATTN_STAMP(2);
@@ -921,21 +922,6 @@ __device__ __forceinline__ float dot8(const uint4& x, const uint4& y) {
   const float4 a0 = raw4(make_uint2(x.x, x.y)), a1 = raw4(make_uint2(x.z, x.w)), b0 = raw4(make_uint2(y.x, y.y)), b1 = raw4(make_uint2(y.z, y.w));
   return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
 }
-// Fragment of the TRANSPOSE of a row-major image (st_rows: 128-byte rows, kswz swizzle) for the MFMA whose B operand comes from a
-// pair (2j, 2j+1) of score tiles, through the gfx950 transposing read ds_read_b64_tr_b16: the 16 lanes of group g supply rows 32j + 4g .. +3 (lane: row c16 >> 2, columns 4 (c16 & 3) .. +3 of the
-// d-tile) and each receives ITS column d = 16 dt + c16 of those four rows; the second read is the same rows 16 further on
-// ((row + 16) has the same swizzle).  Round 3: replaces the transposed images (a second set of global loads and 32 two-byte LDS
-// writes per thread and image) in both backward kernels, as attention_mfma_direct_kernel does for V in the forward.
-__device__ __forceinline__ bf16x8 tfrag_rm(const char* S, int dt, int c16, int j, int g) {
-  typedef short v4s __attribute__((ext_vector_type(4)));
-  const int row = 32 * j + 4 * g + (c16 >> 2), col = dt * 16 + 4 * (c16 & 3);
-  const char* p = S + kswz(row, col >> 3) + ((col & 7) << 1);
-  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
-  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 16 * 128));
-  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-  return __builtin_bit_cast(bf16x8, make_uint4(l2.x, l2.y, h2.x, h2.y));
-}
-
 template <bool DROP>
 __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBwdArgs ba) {
   AttnArgs a = ba.f;
