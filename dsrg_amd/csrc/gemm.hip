@@ -905,7 +905,10 @@ int plan_tiles(GemmArgs& a, int& bm, int& bn, int& nst, bool bf16, int fbm, int 
       e = (wide_env && !fuse) ? wide_env : (bf16 ? wide_def : nullptr);      // fp32 parity mode: 64x64x3 (3.95 vs 4.28 ms per step)
     }
     else if (!only64 && !fuse_a && maxM > 64 && minK >= 2048) e = (longk_env && !fuse) ? longk_env : (bf16 || !fuse ? "128x64x4:1" : nullptr);    // FFN-out: 1.136 -> 1.128 ms per c2 step
-    else if (!fuse && maxM > 64 && maxK <= 1024) { static const char* narrow_env = getenv("DSRG_GEMM_NARROW"); e = narrow_env; }
+    // Narrow-N launches without a LayerNorm epilogue (the pre-training step's plain projections over thousands of token rows):
+    // 128x128x2 once that still gives 300 tiles - c4 10.10 -> 10.00 ms same box, nav-steps unchanged (their plain launches are
+    // smaller); DSRG_GEMM_NARROW overrides ("0" = 64x64 only).
+    else if (!fuse && maxM > 64 && maxK <= 1024) { static const char* narrow_env = getenv("DSRG_GEMM_NARROW"); e = narrow_env ? narrow_env : (bf16 ? "128x128x2:300" : nullptr); }
     while (e && *e) {
       int tbm = 0, tbn = 0, tnst = 0, tmin = 0;
       if (sscanf(e, "%dx%dx%d:%d", &tbm, &tbn, &tnst, &tmin) == 4) {
