@@ -284,6 +284,7 @@ def test_attention_grouped(K, dtype):
 @pytest.mark.parametrize('B,nh,Nq,Nk,mode,sprel', [
     (4, 12, 20, 80, 1, False), (4, 12, 38, 38, 1, False), (4, 12, 20, 20, 1, True), (3, 12, 36, 36, 2, False),
     (3, 2, 108, 108, 3, False), (2, 12, 100, 250, 1, False), (3, 12, 1, 5, 0, False), (2, 2, 70, 130, 1, True),
+    (2, 2, 200, 150, 1, False), (1, 3, 257, 257, 1, True),      # more than one 128-query chunk in the dK / dV kernel
 ])
 def test_attention_bwd(K, dtype, B, nh, Nq, Nk, mode, sprel):
     """dsrg_attention_bwd (recompute from the forward's log-sum-exp) against torch autograd of the fp32 reference."""
