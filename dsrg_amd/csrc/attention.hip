@@ -922,17 +922,18 @@ __device__ __forceinline__ float dot8(const uint4& x, const uint4& y) {
   const float4 a0 = raw4(make_uint2(x.x, x.y)), a1 = raw4(make_uint2(x.z, x.w)), b0 = raw4(make_uint2(y.x, y.y)), b1 = raw4(make_uint2(y.z, y.w));
   return a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
 }
+// (device functions: both run as roles of ONE launch, attention_bwd_mfma_kernel below; `smem` = 2 row images + 2 x KC floats)
 template <bool DROP>
-__global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBwdArgs ba) {
+__device__ __forceinline__ void attention_bwd_mfma_dq_body(const AttnBwdArgs& ba, const int bx, char* smem) {
   AttnArgs a = ba.f;
   if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
-  __shared__ __attribute__((aligned(16))) char Ks[KC * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[KC * 128];
-  __shared__ float mt[KC];
+  char* Ks = smem;
+  char* Vs = smem + KC * 128;
+  float* mt = reinterpret_cast<float*>(smem + 2 * KC * 128);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const int q0 = (bx * 4 + wave) * 16;
   const bool active = q0 < a.Nq;                               // wave-uniform
   const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
@@ -1053,22 +1054,23 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dq_kernel(const AttnBw
 }
 
 template <bool DROP>
-__global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnBwdArgs ba) {
+__device__ __forceinline__ void attention_bwd_mfma_dkv_body(const AttnBwdArgs& ba, const int bx, char* smem) {
   AttnArgs a = ba.f;
   if (a.p_drop > 0.f && a.seed_off) a.seed += *a.seed_off;
-  __shared__ __attribute__((aligned(16))) char Qs[KC * 128];
-  __shared__ __attribute__((aligned(16))) char Gs[KC * 128];
-  __shared__ __attribute__((aligned(16))) float Ls[KC];
-  __shared__ __attribute__((aligned(16))) float Dl[KC];
+  char* Qs = smem;
+  char* Gs = smem + KC * 128;
+  float* Ls = reinterpret_cast<float*>(smem + 2 * KC * 128);
+  float* Dl = Ls + KC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int kb = (blockIdx.x * 4 + wave) * 16;
+  const int kb = (bx * 4 + wave) * 16;
   const bool active = kb < a.Nk;                               // wave-uniform
   const bf16_t* Qp = reinterpret_cast<const bf16_t*>(a.Q) + b * a.q_bs + h * DH;
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(a.K) + b * a.k_bs + h * DH;
   const bf16_t* Vp = reinterpret_cast<const bf16_t*>(a.V) + b * a.v_bs + h * DH;
   const bf16_t* Gp = reinterpret_cast<const bf16_t*>(ba.dO) + b * ba.do_bs + h * DH;
+  const bf16_t* Op = reinterpret_cast<const bf16_t*>(a.O) + b * a.o_bs + h * DH;
   const int key = kb + c16, kc_ = min(key, a.Nk - 1);
   // this lane's key row of K and V; its mask term (-inf: key beyond Nk or masked with -inf -> P = 0)
   uint4 kf[2], vf[2];
@@ -1098,17 +1100,31 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
     const int nq = min(KC, a.Nq - q0);
     const int ntile = ((nq + 31) / 32) * 2;
     {
-      RowRegs qr, gr;
+      // delta = dO . O per query row is formed HERE, from the dO rows that are staged anyway and the matching O rows (a thread
+      // holds one 8-column chunk of rows r, r+32, r+64, r+96; the 8 lanes of a row add their pieces in the dQ role's order:
+      // chunks c and c+4 first, then pairs), so this role does not wait for the dQ role's delta and both run in one launch
+      RowRegs qr, gr, orr;
       ld_rows(qr, Qp, a.q_rs, q0, nq, tid);
       ld_rows(gr, Gp, ba.do_rs, q0, nq, tid);
+      ld_rows(orr, Op, a.o_rs, q0, nq, tid);
       const size_t li = ((size_t)b * a.NH + h) * a.Nq + q0 + min(tid & (KC - 1), nq - 1);
-      const float lv = a.lse[li], dl = ba.delta[li];
+      const float lv = a.lse[li];
+      float dl[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float d = dot8(gr.r[p], orr.r[p]);
+        d += __shfl_xor(d, 4);
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        dl[p] = d;
+      }
       if (q0) __syncthreads();                                 // every wave is done with the previous chunk
       st_rows(Qs, qr, nq, ntile, tid);
       st_rows(Gs, gr, nq, ntile, tid);
-      if (tid < KC) {
-        Ls[tid] = tid < nq ? lv : INFINITY;                    // exp(s - inf) = 0 for the padding rows
-        Dl[tid] = tid < nq ? dl : 0.f;
+      if (tid < KC) Ls[tid] = tid < nq ? lv : INFINITY;        // exp(s - inf) = 0 for the padding rows
+      if ((tid & 7) == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) Dl[(tid >> 3) + 32 * p] = (tid >> 3) + 32 * p < nq ? dl[p] : 0.f;
       }
     }
     __syncthreads();
@@ -1176,6 +1192,16 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_dkv_kernel(const AttnB
       st4(dVp + dt * 16 + 4 * g, make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]));
     }
   }
+}
+
+// One launch for both roles (late round 3): workgroups [0, nqb) compute dQ (and store delta, an output of the entry points),
+// the others dK / dV.  As two launches the second waited for the first (it read the first one's delta) and each ran on
+// 2-3 waves per SIMD: 26 launch pairs of ~20 us each per pre-training step, latency- not throughput-bound.
+template <bool DROP>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const AttnBwdArgs ba, const int nqb) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KC * 128 + 2 * KC * 4];
+  if ((int)blockIdx.x < nqb) attention_bwd_mfma_dq_body<DROP>(ba, blockIdx.x, smem);
+  else attention_bwd_mfma_dkv_body<DROP>(ba, blockIdx.x - nqb, smem);
 }
 
 }  // namespace
@@ -1322,13 +1348,21 @@ static int attention_bwd_impl(const void* Q, int64_t q_bs, int q_rs, const void*
                        k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0 && do_bs % 8 == 0 &&
                        (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O | (uintptr_t)dO) & 15) == 0;
   if (mfma_ok) {
-    dim3 mq((Nq + 63) / 64, NH, B), mk((Nk + 63) / 64, NH, B);
-    if (p_drop > 0.f) {
-      hipLaunchKernelGGL((attention_bwd_mfma_dq_kernel<true>), mq, block, 0, s, ba);
-      hipLaunchKernelGGL((attention_bwd_mfma_dkv_kernel<true>), mk, block, 0, s, ba);
+    const int nqb = (Nq + 63) / 64, nkb = (Nk + 63) / 64;
+    static const char* merged_env = getenv("DSRG_ATTN_BWD_MERGED");      // 0: the two roles as two launches (A/B)
+    if (!merged_env || merged_env[0] != '0') {
+      dim3 mg(nqb + nkb, NH, B);
+      if (p_drop > 0.f) hipLaunchKernelGGL((attention_bwd_mfma_kernel<true>), mg, block, 0, s, ba, nqb);
+      else hipLaunchKernelGGL((attention_bwd_mfma_kernel<false>), mg, block, 0, s, ba, nqb);
     } else {
-      hipLaunchKernelGGL((attention_bwd_mfma_dq_kernel<false>), mq, block, 0, s, ba);
-      hipLaunchKernelGGL((attention_bwd_mfma_dkv_kernel<false>), mk, block, 0, s, ba);
+      dim3 mq(nqb, NH, B), mk(nkb, NH, B);
+      if (p_drop > 0.f) {
+        hipLaunchKernelGGL((attention_bwd_mfma_kernel<true>), mq, block, 0, s, ba, nqb);
+        hipLaunchKernelGGL((attention_bwd_mfma_kernel<true>), mk, block, 0, s, ba, 0);
+      } else {
+        hipLaunchKernelGGL((attention_bwd_mfma_kernel<false>), mq, block, 0, s, ba, nqb);
+        hipLaunchKernelGGL((attention_bwd_mfma_kernel<false>), mk, block, 0, s, ba, 0);
+      }
     }
     DSRG_LAUNCH_CHECK("dsrg_attention_bwd");
     return DSRG_OK;

@@ -452,8 +452,10 @@ int dsrg_act_bwd(const void* z, const void* dy, void* dz, int64_t n, int act, in
 
 /* Attention backward: dQ, dK, dV (contiguous [B,N,NH*64], storage dtype) and, when pair_dists is given, the two
  * gradients of sprel_linear accumulated with float atomics into dsprel[2] (zeroed by the caller).  Scores are
- * recomputed from Q, K, V and the forward's lse; delta_ws is an fp32 [B,NH,Nq] workspace.  O / dO are the forward
- * output and its gradient (strides like the forward). */
+ * recomputed from Q, K, V and the forward's lse; delta_ws is an fp32 [B,NH,Nq] workspace that receives delta = dO . O per
+ * query row (the fp32 path's dK / dV launch reads it back; the bf16 matrix-core path is ONE launch whose dK / dV workgroups
+ * form their own delta from the dO and O rows they stage, and only stores it).  O / dO are the forward output and its
+ * gradient (strides like the forward). */
 int dsrg_attention_bwd(const void* Q, int64_t q_bs, int q_rs, const void* K, int64_t k_bs, int k_rs,
                        const void* V, int64_t v_bs, int v_rs, const void* O, int64_t o_bs, int o_rs,
                        const void* dO, int64_t do_bs, int do_rs, const float* lse,
