@@ -890,17 +890,18 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const AttnBwdArg
 
 // ------------------------------------------------------------------------------------------------
 // bf16 attention backward on the matrix cores (the fp32 kernels above stay the exact-fp32 parity path and the fallback
-// for operands that are not 16-byte aligned).  Same two-launch split and the same recompute from the forward's
-// log-sum-exp; both kernels reuse the forward kernel's operand tricks:
+// for operands that are not 16-byte aligned).  The same split into a dQ part and a dK / dV part and the same recompute from the
+// forward's log-sum-exp, but as two ROLES of one launch (attention_bwd_mfma_kernel below); both reuse the forward kernel's
+// operand tricks:
 //   * a score tile leaves the MFMA with one operand's row index in the lane (c = lane & 15) and the other's in the
 //     register index (4g + r), so per-lane scalars (lse / delta of the lane's query, or the mask term of the lane's key)
 //     apply to all of a lane's accumulators;
 //   * the element-wise result (dS, or P) goes STRAIGHT from those accumulators into the B operand of the next MFMA whose
 //     contraction runs over the register index; the other operand is the transpose of a row-major LDS image, read with the
 //     matching k-slot permutation by two ds_read_b64_tr_b16 sixteen rows apart (tfrag_rm), as the direct forward does for P.V.
-// attention_bwd_mfma_dq : grid (ceil(Nq/64), NH, B), wave <-> 16 queries, keys in chunks of 128:
+// attention_bwd_mfma_dq_body : workgroups [0, ceil(Nq/64)) x NH x B, wave <-> 16 queries, keys in chunks of 128:
 //     S^T = K Q^T, dP^T = V dO^T (accumulators: rows = keys, lane = query), dS^T -> B operand of dQ^T += K^T dS^T.
-// attention_bwd_mfma_dkv: grid (ceil(Nk/64), NH, B), wave <-> 16 keys, queries in chunks of 128:
+// attention_bwd_mfma_dkv_body: the next ceil(Nk/64) workgroups x NH x B, wave <-> 16 keys, queries in chunks of 128:
 //     S = Q K^T, dP = dO V^T (rows = queries, lane = key), P and dS -> B operands of dV^T += dO^T P, dK^T += Q^T dS.
 struct RowRegs { uint4 r[4]; };
 
